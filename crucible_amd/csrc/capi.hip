@@ -1,0 +1,567 @@
+// capi.hip -- C ABI of include/crucible_hip.h over the gfx950 kernels in pathtrace.hpp.
+// Host side of the boundary: deep-copies the scene description, filters hidden
+// primitives, builds the BVH in the reference's topology, lays the scene out for the
+// device, launches the persistent kernel and writes PPM P3.
+//
+// Nothing here falls back to a CPU renderer: without a HIP device cr_create fails.
+#include "../../include/crucible_hip.h"
+#include "pathtrace.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace cr;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+template <typename real> struct DevScene {
+    bool built = false;
+    DevBuf entries, prims, mats, texs, keys;
+    int32_t n_entries = 0, n_prims = 0, n_mats = 0, n_texs = 0, n_scene_keys = 0;
+    size_t lds_bytes = 0;
+    bool animated = false;
+    void release() { entries.release(); prims.release(); mats.release(); texs.release(); keys.release(); built = false; }
+};
+
+}   // namespace
+
+struct CrHandle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n_cus = 0;
+    std::string error;
+    // host copy of the scene description
+    bool has_scene = false;
+    std::vector<CrPrimitive> prims;
+    std::vector<CrMaterial> materials;
+    std::vector<CrTexture> textures;
+    std::vector<CrKeyframe> keys;
+    int32_t sky_kind = 0, sky_image = -1;
+    // images are precision independent
+    DevBuf images, texels;
+    int32_t n_images = 0;
+    DevScene<float> s32;
+    DevScene<double> s64;
+    DevBuf work_counter, counters, att_stack, out_buf;
+    double upload_ms = 0;
+    size_t lds_limit = 64 * 1024;
+    int blocks_per_cu_override = 0;
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                                      \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            (h)->error = std::string(#expr) + ": " + hipGetErrorString(_e);                   \
+            return CR_ERR_HIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+int32_t fail(CrHandle* h, int32_t code, const std::string& msg) {
+    if (h) h->error = msg; else g_create_error = msg;
+    return code;
+}
+
+template <typename real> DevScene<real>& dev_scene(CrHandle* h);
+template <> DevScene<float>& dev_scene<float>(CrHandle* h) { return h->s32; }
+template <> DevScene<double>& dev_scene<double>(CrHandle* h) { return h->s64; }
+
+// ---------------------------------------------------------------- BVH build
+// BVHWrapper::help_generate (src/objects/bvhwrapper.rs:46-78) emitted as a threaded
+// pre-order array.  Node box = union of the range's construction-time primitive boxes
+// (:47-50); axis = longest_axis with strict '>' (bvh.rs:82-94); span 1 and 2 become
+// leaves without sorting (:58-63); span >= 3: stable sort by box min on the axis
+// (sort_by is stable, :66-67), mid = start + span/2 (:71).
+template <typename real> struct Builder {
+    std::vector<real> bmin[3], bmax[3];
+    std::vector<int32_t> order;
+    std::vector<Entry<real>> entries;
+
+    void build(int32_t start, int32_t end) {
+        real lo[3], hi[3];
+        for (int a = 0; a < 3; a++) { lo[a] = r_inf(real(0)); hi[a] = -r_inf(real(0)); }
+        for (int32_t i = start; i < end; i++) {
+            int32_t p = order[i];
+            for (int a = 0; a < 3; a++) {   // Interval::tight_enclose, utils.rs:629-633
+                lo[a] = lo[a] <= bmin[a][p] ? lo[a] : bmin[a][p];
+                hi[a] = hi[a] >= bmax[a][p] ? hi[a] : bmax[a][p];
+            }
+        }
+        real sx = hi[0] - lo[0], sy = hi[1] - lo[1], sz = hi[2] - lo[2];
+        int axis = (sx > sy) ? ((sx > sz) ? 0 : 2) : ((sy > sz) ? 1 : 2);
+        int32_t span = end - start;
+        int32_t idx = (int32_t)entries.size();
+        Entry<real> e;
+        e.b[0] = lo[0]; e.b[1] = hi[0]; e.b[2] = lo[1]; e.b[3] = hi[1]; e.b[4] = lo[2]; e.b[5] = hi[2];
+        e.skip = idx + 1; e.leaf = -1;
+        entries.push_back(e);
+        if (span <= 2) { entries[idx].leaf = (start << 1) | (span - 1); return; }
+        const std::vector<real>& key = bmin[axis];
+        std::stable_sort(order.begin() + start, order.begin() + end, [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+        int32_t mid = start + span / 2;
+        build(start, mid);
+        build(mid, end);
+        entries[idx].skip = (int32_t)entries.size();
+    }
+};
+
+template <typename real> int32_t build_dev_scene(CrHandle* h) {
+    DevScene<real>& ds = dev_scene<real>(h);
+    if (ds.built) return CR_OK;
+    auto t_begin = std::chrono::steady_clock::now();
+    // visible primitives, in list order (bvhwrapper.rs:16-26)
+    std::vector<int32_t> vis;
+    for (size_t i = 0; i < h->prims.size(); i++) if (!(h->prims[i].flags & CR_PRIM_HIDDEN)) vis.push_back((int32_t)i);
+    const int32_t n = (int32_t)vis.size();
+    Builder<real> b;
+    for (int a = 0; a < 3; a++) { b.bmin[a].resize(n); b.bmax[a].resize(n); }
+    b.order.resize(n);
+    std::vector<Prim<real>> src(n);
+    bool any_keys = false;
+    for (int32_t i = 0; i < n; i++) {
+        const CrPrimitive& p = h->prims[vis[i]];
+        Prim<real>& q = src[i];
+        for (int k = 0; k < 9; k++) q.g[k] = (real)p.v[k];
+        q.kind_mat = (p.kind & 1) | (p.material << 1);
+        q.key_first = p.key_first; q.key_count = p.key_count;
+        any_keys |= p.key_count > 0;
+        b.order[i] = i;
+        if (p.kind == CR_PRIM_SPHERE) {   // Sphere::new, sphere.rs:29-30; Aabb::new_from_points bvh.rs:44-64
+            real r = q.g[3];
+            for (int a = 0; a < 3; a++) {
+                real lo = q.g[a] + (-r), hi = q.g[a] + r;
+                if (lo <= hi) { b.bmin[a][i] = lo; b.bmax[a][i] = hi; } else { b.bmin[a][i] = hi; b.bmax[a][i] = lo; }
+            }
+        } else {                          // Triangle::new, triangle.rs:28-35 (f64::min/max)
+            for (int a = 0; a < 3; a++) {
+                b.bmax[a][i] = std::fmax(q.g[a], std::fmax(q.g[3 + a], q.g[6 + a]));
+                b.bmin[a][i] = std::fmin(q.g[a], std::fmin(q.g[3 + a], q.g[6 + a]));
+            }
+        }
+    }
+    if (n > 0) b.build(0, n);
+    std::vector<Prim<real>> leaf_prims(n);
+    for (int32_t i = 0; i < n; i++) leaf_prims[i] = src[b.order[i]];
+
+    std::vector<Mat<real>> mats(h->materials.size());
+    for (size_t i = 0; i < mats.size(); i++) {
+        const CrMaterial& m = h->materials[i];
+        Mat<real>& o = mats[i];
+        memset(&o, 0, sizeof o);
+        o.kind = m.kind; o.param = (real)m.param; o.tex = -1;
+        for (int k = 0; k < 3; k++) o.albedo[k] = (real)m.albedo[k];
+        if (m.kind == CR_MAT_LAMBERTIAN) {
+            const CrTexture& t = h->textures[m.texture];
+            if (t.kind == CR_TEX_SOLID) for (int k = 0; k < 3; k++) o.albedo[k] = (real)t.color[k];
+            else o.tex = m.texture;
+        }
+    }
+    std::vector<Tex<real>> texs(h->textures.size());
+    for (size_t i = 0; i < texs.size(); i++) {
+        const CrTexture& t = h->textures[i];
+        Tex<real>& o = texs[i];
+        memset(&o, 0, sizeof o);
+        o.kind = t.kind; o.even = t.even; o.odd = t.odd; o.image = t.image; o.inv_scale = (real)t.inv_scale;
+        for (int k = 0; k < 3; k++) o.color[k] = (real)t.color[k];
+    }
+    // scene keys, then room for the camera's keys (copied per render)
+    const size_t kMaxCamKeys = 512;
+    std::vector<Key<real>> keys(h->keys.size() + kMaxCamKeys);
+    memset(keys.data(), 0, keys.size() * sizeof(Key<real>));
+    for (size_t i = 0; i < h->keys.size(); i++) {
+        const CrKeyframe& k = h->keys[i];
+        keys[i].t0 = (real)k.t0; keys[i].t1 = (real)k.t1; keys[i].a = (real)k.a; keys[i].b = (real)k.b;
+        keys[i].channel = k.channel; keys[i].interp = k.interp;
+    }
+
+    auto up = [&](DevBuf& d, const void* src_p, size_t bytes) -> hipError_t {
+        hipError_t e = d.ensure(bytes ? bytes : 16);
+        if (e != hipSuccess) return e;
+        if (bytes) return hipMemcpy(d.p, src_p, bytes, hipMemcpyHostToDevice);
+        return hipSuccess;
+    };
+    HIP_TRY(h, up(ds.entries, b.entries.data(), b.entries.size() * sizeof(Entry<real>)));
+    HIP_TRY(h, up(ds.prims, leaf_prims.data(), leaf_prims.size() * sizeof(Prim<real>)));
+    HIP_TRY(h, up(ds.mats, mats.data(), mats.size() * sizeof(Mat<real>)));
+    HIP_TRY(h, up(ds.texs, texs.data(), texs.size() * sizeof(Tex<real>)));
+    HIP_TRY(h, up(ds.keys, keys.data(), keys.size() * sizeof(Key<real>)));
+    ds.n_entries = (int32_t)b.entries.size(); ds.n_prims = n; ds.n_mats = (int32_t)mats.size(); ds.n_texs = (int32_t)texs.size();
+    ds.n_scene_keys = (int32_t)h->keys.size();
+    auto r16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    ds.lds_bytes = r16(b.entries.size() * sizeof(Entry<real>)) + r16(leaf_prims.size() * sizeof(Prim<real>)) +
+                   r16(mats.size() * sizeof(Mat<real>)) + r16(texs.size() * sizeof(Tex<real>));
+    ds.animated = any_keys;
+    ds.built = true;
+    h->upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return CR_OK;
+}
+
+template <typename real> void key_to_real(const CrKeyframe& k, Key<real>& o) {
+    o.t0 = (real)k.t0; o.t1 = (real)k.t1; o.a = (real)k.a; o.b = (real)k.b; o.channel = k.channel; o.interp = k.interp;
+}
+
+template <typename real, bool LDS, bool ANIM>
+int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, CrStats* stats) {
+    KernelArgs<real> args = args_in;
+    auto kern = pathtrace_kernel<real, LDS, ANIM>;
+    if (LDS) HIP_TRY(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int per_cu = 0;
+    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, LDS ? lds_bytes : 0));
+    if (per_cu < 1) per_cu = 1;
+    if (h->blocks_per_cu_override > 0) per_cu = h->blocks_per_cu_override;
+    uint32_t total_work = args.tiles_x * args.tiles_y * 64u;
+    uint32_t grid = (uint32_t)(h->n_cus * per_cu);
+    uint32_t need_blocks = (total_work + kBlock - 1) / kBlock;
+    if (grid > need_blocks) grid = need_blocks;
+    if (grid < 1) grid = 1;
+    args.n_threads = grid * kBlock;
+    size_t stack_bytes = (size_t)3 * (size_t)(args.max_depth > 0 ? args.max_depth : 1) * args.n_threads * sizeof(real);
+    HIP_TRY(h, h->att_stack.ensure(stack_bytes));
+    args.att_stack = (real*)h->att_stack.p;
+    HIP_TRY(h, hipMemsetAsync(h->work_counter.p, 0, 4, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 4 * sizeof(uint64_t), h->stream));
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, h->stream, args);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    if (stats) {
+        HIP_TRY(h, hipEventSynchronize(h->ev1));
+        float ms = 0;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        uint64_t c[4];
+        HIP_TRY(h, hipMemcpy(c, h->counters.p, sizeof c, hipMemcpyDeviceToHost));
+        memset(stats, 0, sizeof *stats);
+        stats->kernel_ms = ms;
+        stats->segments = c[0]; stats->node_tests = c[1]; stats->prim_tests = c[2]; stats->texel_fetches = c[3];
+        stats->samples = (uint64_t)args.cam.W * (uint64_t)args.cam.H * (uint64_t)(args.sample_end - args.sample_begin);
+        stats->upload_ms = h->upload_ms;
+        stats->bvh_entries = args.n_entries;
+        stats->scene_in_lds = LDS ? 1 : 0;
+    }
+    return CR_OK;
+}
+
+template <typename real>
+int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* p, void* d_out, CrStats* stats) {
+    int32_t rc = build_dev_scene<real>(h);
+    if (rc != CR_OK) return rc;
+    DevScene<real>& ds = dev_scene<real>(h);
+    KernelArgs<real> a;
+    memset(&a, 0, sizeof a);
+    a.entries = (const Entry<real>*)ds.entries.p; a.prims = (const Prim<real>*)ds.prims.p;
+    a.mats = (const Mat<real>*)ds.mats.p; a.texs = (const Tex<real>*)ds.texs.p;
+    a.images = (const ImageRef*)h->images.p; a.texels = (const uint32_t*)h->texels.p;
+    a.keys = (const Key<real>*)ds.keys.p;
+    a.n_entries = ds.n_entries; a.n_prims = ds.n_prims; a.n_mats = ds.n_mats; a.n_texs = ds.n_texs;
+    a.sky_kind = h->sky_kind; a.sky_image = h->sky_image;
+
+    // camera set-up: Radians::new_from_degrees (utils.rs:51-55), fix_viewport
+    // (rendering_compute.rs:5-11) and defocus_radius (:71-73) in f64, rounded once
+    const double PI64 = 3.14159265358979323846264338327950288;
+    CamConst<real>& c = a.cam;
+    c.W = cd->image_width; c.H = cd->image_height;
+    double vfov = cd->vfov_degrees * PI64 / 180.0;
+    double hh = std::tan(vfov / 2.0);
+    double vh = 2.0 * hh * cd->focus_dist;
+    double vw = vh * ((double)cd->image_width / (double)cd->image_height);
+    double da = cd->defocus_angle_degrees * PI64 / 180.0;
+    c.viewport_height = (real)vh; c.viewport_width = (real)vw; c.focus_dist = (real)cd->focus_dist;
+    c.defocus_on = !(da <= 0.0);
+    c.defocus_radius = (real)(cd->focus_dist * std::tan(da / 2.0));
+    c.from = mk<real>((real)cd->look_from[0], (real)cd->look_from[1], (real)cd->look_from[2]);
+    c.at = mk<real>((real)cd->look_at[0], (real)cd->look_at[1], (real)cd->look_at[2]);
+    c.vup = mk<real>((real)cd->vup[0], (real)cd->vup[1], (real)cd->vup[2]);
+    int nk = cd->from_key_count + cd->at_key_count;
+    c.animated = nk > 0;
+    if (nk > 512) return fail(h, CR_ERR_UNSUPPORTED, "more than 512 camera keyframes");
+    c.from_key_first = ds.n_scene_keys; c.from_key_count = cd->from_key_count;
+    c.at_key_first = ds.n_scene_keys + cd->from_key_count; c.at_key_count = cd->at_key_count;
+    if (nk > 0) {
+        std::vector<Key<real>> ck(nk);
+        for (int i = 0; i < cd->from_key_count; i++) key_to_real(cd->from_keys[i], ck[i]);
+        for (int i = 0; i < cd->at_key_count; i++) key_to_real(cd->at_keys[i], ck[cd->from_key_count + i]);
+        HIP_TRY(h, hipMemcpy((Key<real>*)ds.keys.p + ds.n_scene_keys, ck.data(), nk * sizeof(Key<real>), hipMemcpyHostToDevice));
+    }
+    {   // static camera: same expression tree the kernel would evaluate per sample
+        V3<real> from = mk<real>(real(0) + c.from.x, real(0) + c.from.y, real(0) + c.from.z);
+        V3<real> at = mk<real>(real(0) + c.at.x, real(0) + c.at.y, real(0) + c.at.z);
+        from = scale(real(1), from); at = scale(real(1), at);   // build_other_scaler(1.0): s*x
+        CamFrame<real> f = camera_frame(c, from, at);
+        if (!c.animated) c.from = f.from;
+        c.p00 = f.p00; c.pdu = f.pdu; c.pdv = f.pdv; c.ddu = f.ddu; c.ddv = f.ddv;
+    }
+
+    a.sample_begin = p->sample_begin; a.sample_end = p->sample_begin + p->sample_count;
+    a.samples_total = p->samples; a.max_depth = p->max_depth;
+    a.seed_mixed = mix64(p->seed + RNG_GAMMA);
+    a.current_time = (real)p->frame * (real(1) / (real)p->frame_rate);                       // ray_casting.rs:77
+    a.shutter_length = ((real)p->shutter_angle / real(360)) * (real(1) / (real)p->frame_rate);   // :79
+    a.output_sum = p->output_sum;
+    a.tiles_x = (uint32_t)(c.W + 7) / 8u; a.tiles_y = (uint32_t)(c.H + 7) / 8u;
+    a.work_counter = (uint32_t*)h->work_counter.p;
+    a.counters = (uint64_t*)h->counters.p;
+    a.out = (real*)d_out;
+
+    const bool anim = ds.animated || c.animated;
+    const bool lds = ds.lds_bytes <= h->lds_limit && ds.n_entries > 0;
+    if (lds) return anim ? launch<real, true, true>(h, a, ds.lds_bytes, stats) : launch<real, true, false>(h, a, ds.lds_bytes, stats);
+    return anim ? launch<real, false, true>(h, a, 0, stats) : launch<real, false, false>(h, a, 0, stats);
+}
+
+int32_t validate_render(CrHandle* h, const CrCameraDesc* cam, const CrRenderParams* p) {
+    if (!h) return CR_ERR_INVALID_ARG;
+    if (!cam || !p) return fail(h, CR_ERR_INVALID_ARG, "null camera or params");
+    if (!h->has_scene) return fail(h, CR_ERR_NO_SCENE, "cr_render before cr_upload_scene");
+    if (cam->image_width < 1 || cam->image_height < 1) return fail(h, CR_ERR_INVALID_ARG, "image size must be positive");
+    if ((int64_t)cam->image_width * cam->image_height > (int64_t)1 << 26) return fail(h, CR_ERR_INVALID_ARG, "image too large");
+    if (p->samples < 1) return fail(h, CR_ERR_INVALID_ARG, "The camera must have a positive number of samples.");   // camera/mod.rs:235-238
+    if (p->sample_begin < 0 || p->sample_count < 0 || p->sample_begin + p->sample_count > p->samples)
+        return fail(h, CR_ERR_INVALID_ARG, "sample range outside [0, samples)");
+    if (p->max_depth < 0) return fail(h, CR_ERR_INVALID_ARG, "max_depth must be >= 0");
+    if (p->real_type != CR_REAL_F32 && p->real_type != CR_REAL_F64) return fail(h, CR_ERR_INVALID_ARG, "unknown real_type");
+    if (!(p->frame_rate > 0)) return fail(h, CR_ERR_INVALID_ARG, "frame_rate must be positive");
+    if ((cam->from_key_count > 0 && !cam->from_keys) || (cam->at_key_count > 0 && !cam->at_keys) || cam->from_key_count < 0 || cam->at_key_count < 0)
+        return fail(h, CR_ERR_INVALID_ARG, "camera keyframe array missing");
+    return CR_OK;
+}
+
+size_t real_size(int32_t real_type) { return real_type == CR_REAL_F64 ? sizeof(double) : sizeof(float); }
+
+uint32_t display_byte(double c) {   // impl Display for Color, utils.rs:422-437: (255.0 * c.sqrt()) as u32
+    double v = 255.0 * std::sqrt(c);
+    if (!(v == v) || v <= 0.0) return 0;
+    if (v >= 4294967295.0) return 4294967295u;
+    return (uint32_t)v;
+}
+
+}   // namespace
+
+extern "C" {
+
+int32_t cr_abi_version(void) { return CR_ABI_VERSION; }
+
+int32_t cr_create(int32_t device_id, CrHandle** out) {
+    if (!out) return fail(nullptr, CR_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev < 1) return fail(nullptr, CR_ERR_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n_dev) return fail(nullptr, CR_ERR_INVALID_ARG, "device_id out of range");
+    CrHandle* h = new CrHandle();
+    h->device = device_id;
+    auto bail = [&](const char* what, hipError_t err) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+        delete h;
+        return CR_ERR_HIP;
+    };
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    h->n_cus = prop.multiProcessorCount;
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = h->work_counter.ensure(16)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = h->counters.ensure(64)) != hipSuccess) return bail("hipMalloc", e);
+    if (const char* s = getenv("CRUCIBLE_LDS_LIMIT")) h->lds_limit = (size_t)atol(s);
+    if (const char* s = getenv("CRUCIBLE_BLOCKS_PER_CU")) h->blocks_per_cu_override = atoi(s);
+    *out = h;
+    return CR_OK;
+}
+
+void cr_destroy(CrHandle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->s32.release(); h->s64.release();
+    h->images.release(); h->texels.release(); h->work_counter.release(); h->counters.release();
+    h->att_stack.release(); h->out_buf.release();
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int32_t cr_upload_scene(CrHandle* h, const CrSceneDesc* s) {
+    if (!h) return CR_ERR_INVALID_ARG;
+    if (!s) return fail(h, CR_ERR_INVALID_ARG, "scene is null");
+    if (s->n_prims < 0 || s->n_materials < 0 || s->n_textures < 0 || s->n_images < 0 || s->n_keys < 0)
+        return fail(h, CR_ERR_INVALID_ARG, "negative count");
+    if (s->n_prims >= (1 << 30)) return fail(h, CR_ERR_INVALID_ARG, "too many primitives");
+    auto finite = [](double x) { return x == x && x != HUGE_VAL && x != -HUGE_VAL; };
+    for (int i = 0; i < s->n_textures; i++) {
+        const CrTexture& t = s->textures[i];
+        if (t.kind < CR_TEX_SOLID || t.kind > CR_TEX_IMAGE) return fail(h, CR_ERR_INVALID_ARG, "unknown texture kind");
+        // children before parents keeps the texture graph acyclic (Arc<Textures> cannot cycle either)
+        if (t.kind == CR_TEX_CHECKER && (t.even < 0 || t.even >= i || t.odd < 0 || t.odd >= i))
+            return fail(h, CR_ERR_INVALID_ARG, "checker sub-textures must have smaller indices");
+        if (t.kind == CR_TEX_IMAGE && (t.image < 0 || t.image >= s->n_images)) return fail(h, CR_ERR_INVALID_ARG, "texture image index out of range");
+        if (t.kind == CR_TEX_SOLID) for (int k = 0; k < 3; k++) if (!(t.color[k] >= 0.0 && t.color[k] <= 1.0))
+            return fail(h, CR_ERR_INVALID_ARG, "colour component outside [0,1]");   // Color::new, utils.rs:345-350
+    }
+    for (int i = 0; i < s->n_materials; i++) {
+        const CrMaterial& m = s->materials[i];
+        if (m.kind < CR_MAT_LAMBERTIAN || m.kind > CR_MAT_DIELECTRIC) return fail(h, CR_ERR_INVALID_ARG, "unknown material kind");
+        if (m.kind == CR_MAT_LAMBERTIAN && (m.texture < 0 || m.texture >= s->n_textures)) return fail(h, CR_ERR_INVALID_ARG, "material texture index out of range");
+        if (m.kind == CR_MAT_METAL) {
+            if (!(m.param <= 1.0)) return fail(h, CR_ERR_INVALID_ARG, "A metal cannot have a fuzz factor above 1.0");   // metal.rs:21
+            if (!(m.param >= 0.0)) return fail(h, CR_ERR_INVALID_ARG, "A metal cannot have a fuzz factor below 0.0");   // metal.rs:22
+            for (int k = 0; k < 3; k++) if (!(m.albedo[k] >= 0.0 && m.albedo[k] <= 1.0)) return fail(h, CR_ERR_INVALID_ARG, "colour component outside [0,1]");
+        }
+        if (!finite(m.param)) return fail(h, CR_ERR_INVALID_ARG, "material parameter is not finite");
+    }
+    for (int i = 0; i < s->n_keys; i++) {
+        const CrKeyframe& k = s->keys[i];
+        if (k.channel < CR_KEY_TX || k.channel > CR_KEY_RADIUS || (k.interp != CR_KEY_NERP && k.interp != CR_KEY_LERP))
+            return fail(h, CR_ERR_INVALID_ARG, "bad keyframe");
+    }
+    for (int i = 0; i < s->n_prims; i++) {
+        const CrPrimitive& p = s->prims[i];
+        if (p.kind != CR_PRIM_SPHERE && p.kind != CR_PRIM_TRIANGLE) return fail(h, CR_ERR_INVALID_ARG, "unknown primitive kind");
+        if (p.material < 0 || p.material >= s->n_materials) return fail(h, CR_ERR_INVALID_ARG, "primitive material index out of range");
+        if (p.key_count < 0 || p.key_first < 0 || p.key_first + p.key_count > s->n_keys) return fail(h, CR_ERR_INVALID_ARG, "primitive keyframe range out of bounds");
+        int nv = p.kind == CR_PRIM_SPHERE ? 4 : 9;
+        for (int k = 0; k < nv; k++) if (!finite(p.v[k])) return fail(h, CR_ERR_INVALID_ARG, "primitive coordinate is not finite");
+        if (p.kind == CR_PRIM_SPHERE && !(p.v[3] >= 0.0)) return fail(h, CR_ERR_INVALID_ARG, "Cannot make a sphere with negative radius");   // sphere.rs:26
+    }
+    if (s->sky_kind != CR_SKY_DEFAULT && s->sky_kind != CR_SKY_SPHERICAL) return fail(h, CR_ERR_INVALID_ARG, "unknown sky kind");
+    if (s->sky_kind == CR_SKY_SPHERICAL && (s->sky_image < 0 || s->sky_image >= s->n_images)) return fail(h, CR_ERR_INVALID_ARG, "sky image index out of range");
+    for (int i = 0; i < s->n_images; i++)
+        if (s->images[i].width < 1 || s->images[i].height < 1 || !s->images[i].rgb8) return fail(h, CR_ERR_INVALID_ARG, "bad image");
+
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    auto t_begin = std::chrono::steady_clock::now();
+    h->prims.assign(s->prims, s->prims + s->n_prims);
+    h->materials.assign(s->materials, s->materials + s->n_materials);
+    h->textures.assign(s->textures, s->textures + s->n_textures);
+    h->keys.assign(s->keys, s->keys + s->n_keys);
+    h->sky_kind = s->sky_kind; h->sky_image = s->sky_image;
+    h->s32.built = false; h->s64.built = false;
+    // images: RGB8 -> RGBA8 words, one flat texel array
+    std::vector<ImageRef> refs(s->n_images);
+    size_t total = 0;
+    for (int i = 0; i < s->n_images; i++) {
+        refs[i].w = s->images[i].width; refs[i].h = s->images[i].height; refs[i].offset = (uint32_t)total; refs[i].pad = 0;
+        total += (size_t)s->images[i].width * s->images[i].height;
+    }
+    if (total >= ((size_t)1 << 32)) return fail(h, CR_ERR_INVALID_ARG, "too many texels");
+    std::vector<uint32_t> texels(total ? total : 1);
+    for (int i = 0; i < s->n_images; i++) {
+        const uint8_t* src = s->images[i].rgb8;
+        size_t n = (size_t)refs[i].w * refs[i].h;
+        uint32_t* dst = texels.data() + refs[i].offset;
+        for (size_t k = 0; k < n; k++) dst[k] = (uint32_t)src[3 * k] | ((uint32_t)src[3 * k + 1] << 8) | ((uint32_t)src[3 * k + 2] << 16);
+    }
+    HIP_TRY(h, h->images.ensure(refs.size() * sizeof(ImageRef) + 16));
+    HIP_TRY(h, h->texels.ensure(texels.size() * 4));
+    if (!refs.empty()) HIP_TRY(h, hipMemcpy(h->images.p, refs.data(), refs.size() * sizeof(ImageRef), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->texels.p, texels.data(), texels.size() * 4, hipMemcpyHostToDevice));
+    h->n_images = s->n_images;
+    h->has_scene = true;
+    h->upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return CR_OK;
+}
+
+int32_t cr_render_device(CrHandle* h, const CrCameraDesc* cam, const CrRenderParams* p, void* d_out, CrStats* stats) {
+    int32_t rc = validate_render(h, cam, p);
+    if (rc != CR_OK) return rc;
+    if (!d_out) return fail(h, CR_ERR_INVALID_ARG, "output buffer is null");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (p->real_type == CR_REAL_F64) return render_typed<double>(h, cam, p, d_out, stats);
+    return render_typed<float>(h, cam, p, d_out, stats);
+}
+
+int32_t cr_render_host(CrHandle* h, const CrCameraDesc* cam, const CrRenderParams* p, void* h_out, CrStats* stats) {
+    int32_t rc = validate_render(h, cam, p);
+    if (rc != CR_OK) return rc;
+    if (!h_out) return fail(h, CR_ERR_INVALID_ARG, "output buffer is null");
+    HIP_TRY(h, hipSetDevice(h->device));
+    size_t n = (size_t)cam->image_width * cam->image_height * 3;
+    size_t bytes = n * real_size(p->real_type);
+    HIP_TRY(h, h->out_buf.ensure(bytes));
+    CrStats local;
+    rc = cr_render_device(h, cam, p, h->out_buf.p, stats ? stats : &local);
+    if (rc != CR_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h_out, h->out_buf.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!p->output_sum) {   // Color::new asserts 0 <= c <= 1 on every mean (ray_casting.rs:172)
+        uint64_t bad = 0;
+        size_t n_pix = n / 3;
+        for (size_t i = 0; i < n_pix; i++) {
+            bool ok = true;
+            for (int k = 0; k < 3; k++) {
+                double v = p->real_type == CR_REAL_F64 ? ((const double*)h_out)[3 * i + k] : (double)((const float*)h_out)[3 * i + k];
+                ok = ok && (v >= 0.0 && v <= 1.0);
+            }
+            bad += ok ? 0 : 1;
+        }
+        if (stats) stats->nan_pixels = bad;
+        if (bad) return fail(h, CR_ERR_NAN, "a pixel mean is NaN or outside [0,1] (the reference panics in Color::new)");
+    }
+    return CR_OK;
+}
+
+int32_t cr_synchronize(CrHandle* h) {
+    if (!h) return CR_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CR_OK;
+}
+
+void* cr_stream(CrHandle* h) { return h ? (void*)h->stream : nullptr; }
+
+int32_t cr_quantize_rgb8(const void* rgb, int32_t real_type, int64_t n_pixels, uint8_t* out) {
+    if (!rgb || !out || n_pixels < 0 || (real_type != CR_REAL_F32 && real_type != CR_REAL_F64)) return CR_ERR_INVALID_ARG;
+    for (int64_t i = 0; i < n_pixels * 3; i++) {
+        double v = real_type == CR_REAL_F64 ? ((const double*)rgb)[i] : (double)((const float*)rgb)[i];
+        uint32_t b = display_byte(v);
+        out[i] = (uint8_t)(b > 255u ? 255u : b);
+    }
+    return CR_OK;
+}
+
+int32_t cr_write_ppm(const char* path, const void* rgb, int32_t real_type, int32_t w, int32_t hgt) {
+    if (!path || !rgb || w < 1 || hgt < 1 || (real_type != CR_REAL_F32 && real_type != CR_REAL_F64)) return CR_ERR_INVALID_ARG;
+    FILE* f = fopen(path, "w");   // OpenOptions write+create+truncate, camera/mod.rs:275-279
+    if (!f) return CR_ERR_IO;
+    std::vector<char> buf(1 << 20);
+    setvbuf(f, buf.data(), _IOFBF, buf.size());
+    bool ok = fprintf(f, "P3\n%d %d\n255\n", w, hgt) > 0;   // camera/mod.rs:286
+    for (int64_t i = 0; ok && i < (int64_t)w * hgt; i++) {  // row-major, j outer (camera/mod.rs:306-311)
+        double c[3];
+        for (int k = 0; k < 3; k++) c[k] = real_type == CR_REAL_F64 ? ((const double*)rgb)[3 * i + k] : (double)((const float*)rgb)[3 * i + k];
+        ok = fprintf(f, "%u %u %u\n", display_byte(c[0]), display_byte(c[1]), display_byte(c[2])) > 0;
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? CR_OK : CR_ERR_IO;
+}
+
+const char* cr_last_error(CrHandle* h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+}   // extern "C"

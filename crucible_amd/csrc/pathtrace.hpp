@@ -1,0 +1,640 @@
+// pathtrace.hpp -- the gfx950 path-tracing megakernel and the math it shares with
+// the host-side camera set-up.  Hand-written for CDNA4: wave64, one persistent
+// launch, scene staged in LDS when it fits, stackless fixed-order BVH walk,
+// ballot/prefix regeneration of finished lanes.  No MFMA (branchy traversal).
+//
+// Reference semantics (citations relative to the Crucible tree):
+//   Camera::cast_ray / ray_color / average_samples   src/camera/ray_casting.rs:64-173
+//   viewport + basis math                            src/camera/rendering_compute.rs
+//   BVHWrapper::hit, Aabb::hit                       src/objects/bvhwrapper.rs:96-126, bvh.rs:96-132
+//   Sphere::hit, Triangle::hit                       src/objects/sphere.rs:60-105, triangle.rs:84-140
+//   Materials::scatter                               src/materials/{lambertian,metal,dielectric}.rs
+//   Textures::value, SkyboxImage::get_color          src/textures/*.rs, src/scene/mod.rs:37-45
+//   Point3 / Color / Interval arithmetic             src/utils.rs:78-697
+// Every expression keeps the reference's operand order; the build uses
+// -ffp-contract=off so no FMA is formed, and IEEE div/sqrt.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cr {
+
+#define CR_HD __host__ __device__ __forceinline__
+#define CR_D __device__ __forceinline__
+
+// ------------------------------------------------------------------ scalar traits
+template <typename real> struct RealTraits;
+template <> struct RealTraits<float> {
+    static constexpr float eps = 1.1920928955078125e-07f;   // FLT_EPSILON (f32 twin of f64::EPSILON, triangle.rs:101)
+    static constexpr float tiny = 0.0f;                     // 1e-160 rounds to 0 in f32 (utils.rs:131)
+    static constexpr float pi = 3.14159265358979323846f;
+};
+template <> struct RealTraits<double> {
+    static constexpr double eps = 2.220446049250313e-16;    // f64::EPSILON
+    static constexpr double tiny = 1e-160;
+    static constexpr double pi = 3.14159265358979323846;
+};
+
+CR_HD float r_sqrt(float x) { return __builtin_sqrtf(x); }
+CR_HD double r_sqrt(double x) { return __builtin_sqrt(x); }
+CR_HD float r_abs(float x) { return __builtin_fabsf(x); }
+CR_HD double r_abs(double x) { return __builtin_fabs(x); }
+CR_HD float r_floor(float x) { return __builtin_floorf(x); }
+CR_HD double r_floor(double x) { return __builtin_floor(x); }
+CR_HD float r_inf(float) { return __builtin_huge_valf(); }
+CR_HD double r_inf(double) { return __builtin_huge_val(); }
+// f64::min: the non-NaN operand when one is NaN (== fmin)
+CR_HD float r_fmin(float a, float b) { return __builtin_fminf(a, b); }
+CR_HD double r_fmin(double a, double b) { return __builtin_fmin(a, b); }
+
+// ------------------------------------------------------------------ Vec3 (utils.rs:72-340)
+template <typename real> struct V3 { real x, y, z; };
+
+template <typename real> CR_HD V3<real> mk(real x, real y, real z) { return V3<real>{x, y, z}; }
+template <typename real> CR_HD V3<real> neg(V3<real> a) { return mk<real>(-a.x, -a.y, -a.z); }
+template <typename real> CR_HD V3<real> add(V3<real> a, V3<real> b) { return mk<real>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <typename real> CR_HD V3<real> sub(V3<real> a, V3<real> b) { return add(a, neg(b)); }   // self + (-rhs), utils.rs:293-298
+template <typename real> CR_HD V3<real> scale(real s, V3<real> a) { return mk<real>(s * a.x, s * a.y, s * a.z); }
+template <typename real> CR_HD V3<real> divs(V3<real> a, real s) { return scale(real(1) / s, a); }   // (1.0/rhs)*self, utils.rs:335-340
+template <typename real> CR_HD real len2(V3<real> a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+template <typename real> CR_HD real dot(V3<real> a, V3<real> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename real> CR_HD V3<real> cross(V3<real> a, V3<real> b) {
+    return mk<real>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+template <typename real> CR_HD V3<real> unit(V3<real> a) { return divs(a, r_sqrt(len2(a))); }
+template <typename real> CR_HD V3<real> reflect(V3<real> v, V3<real> n) { return sub(v, scale(real(2) * dot(v, n), n)); }   // utils.rs:149-151
+template <typename real> CR_HD V3<real> refract(V3<real> v, V3<real> n, real eta) {   // utils.rs:157-163
+    real cos_theta = r_fmin(dot(neg(v), n), real(1));
+    V3<real> perp = scale(eta, add(v, scale(cos_theta, n)));
+    V3<real> par = scale(-(r_sqrt(r_abs(real(1) - len2(perp)))), n);
+    return add(perp, par);
+}
+
+template <typename real> CR_HD real clamp01(real x) { return x < real(0) ? real(0) : (x > real(1) ? real(1) : x); }   // f64::clamp
+
+// clamped Color ops (utils.rs:445-607); a Color is a V3 with r,g,b in x,y,z
+template <typename real> CR_HD V3<real> c_neg(V3<real> c) {
+    real lo = c.x < c.y ? c.x : c.y; lo = lo < c.z ? lo : c.z;
+    real hi = c.x > c.y ? c.x : c.y; hi = hi > c.z ? hi : c.z;
+    real k = lo + hi;
+    return mk<real>(r_abs(k - c.x), r_abs(k - c.y), r_abs(k - c.z));
+}
+template <typename real> CR_HD V3<real> c_add(V3<real> a, V3<real> b) { return mk<real>(clamp01(a.x + b.x), clamp01(a.y + b.y), clamp01(a.z + b.z)); }
+template <typename real> CR_HD V3<real> c_scale(real s, V3<real> c) {   // impl Mul<Color> for f64
+    V3<real> m = (s < real(0)) ? c_neg(c) : c;
+    real p = r_abs(s);
+    return mk<real>(clamp01(p * m.x), clamp01(p * m.y), clamp01(p * m.z));
+}
+template <typename real> CR_HD V3<real> c_mul(V3<real> a, V3<real> b) { return mk<real>(clamp01(a.x * b.x), clamp01(a.y * b.y), clamp01(a.z * b.z)); }
+template <typename real> CR_HD V3<real> c_div(V3<real> c, real s) {
+    V3<real> m = (s < real(0)) ? c_neg(c) : c;
+    return c_scale(real(1) / r_abs(s), m);
+}
+
+// ------------------------------------------------------------------ RNG (DESIGN.md "RNG")
+// Counter-based SplitMix64: draw n of (seed, pixel, sample) = mix64(key + (n+1)*GAMMA).
+constexpr uint64_t RNG_GAMMA = 0x9E3779B97F4A7C15ULL;
+CR_HD uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+CR_HD uint64_t rng_key(uint64_t seed_mixed, uint32_t pixel, uint32_t sample) {
+    return mix64(seed_mixed ^ (((uint64_t)pixel << 32) | (uint64_t)sample));
+}
+CR_HD float u01(uint64_t u, float) { return (float)(u >> 40) * 0x1.0p-24f; }
+CR_HD double u01(uint64_t u, double) { return (double)(u >> 11) * 0x1.0p-53; }
+template <typename real> CR_HD real rng_uniform(uint64_t& s) { s += RNG_GAMMA; return u01(mix64(s), real(0)); }
+template <typename real> CR_HD real rng_range(uint64_t& s, real lo, real hi) { return lo + (hi - lo) * rng_uniform<real>(s); }
+
+template <typename real> CR_HD V3<real> random_unit_vector(uint64_t& s) {   // utils.rs:127-136
+    for (;;) {
+        real x = rng_range<real>(s, real(-1), real(1));
+        real y = rng_range<real>(s, real(-1), real(1));
+        real z = rng_range<real>(s, real(-1), real(1));
+        V3<real> p = mk<real>(x, y, z);
+        real lensq = len2(p);
+        if (RealTraits<real>::tiny < lensq && lensq <= real(1)) return divs(p, r_sqrt(lensq));
+    }
+}
+
+// ------------------------------------------------------------------ device scene layout
+// Threaded BVH: the reference's wrapper tree (bvhwrapper.rs:46-78) in DFS pre-order.
+// A walk that goes to idx+1 on a box hit and to `skip` on a miss visits exactly the
+// wrappers BVHWrapper::hit visits, in the same order (left subtree, then right).
+// leaf < 0: inner wrapper.  leaf >= 0: span-1 or span-2 wrapper whose children are
+// primitives: first = leaf >> 1, count = (leaf & 1) + 1, in leaf order.
+template <typename real> struct alignas(16) Entry {
+    real b[6];      // xmin, xmax, ymin, ymax, zmin, zmax
+    int32_t skip;
+    int32_t leaf;
+};
+// Primitive record in leaf order.  g[0..3] sphere centre+radius, or g[0..8] a,b,c.
+template <typename real> struct alignas(16) Prim {
+    real g[9];
+    int32_t kind_mat;   // kind in bit 0, material index above it
+    int32_t key_first;
+    int32_t key_count;
+    CR_HD int32_t kind() const { return kind_mat & 1; }
+    CR_HD int32_t mat() const { return kind_mat >> 1; }
+};
+template <typename real> struct alignas(16) Mat {
+    real albedo[3];   // metal albedo, or the lambertian's colour when its texture is solid
+    real param;       // scatter_prob | fuzz | refraction_index
+    int32_t kind;
+    int32_t tex;      // lambertian: texture index, or -1 when albedo[] already holds the solid colour
+    int32_t pad0, pad1;
+};
+template <typename real> struct alignas(16) Tex {
+    real color[3];
+    real inv_scale;
+    int32_t kind, even, odd, image;
+};
+struct ImageRef { int32_t w, h; uint32_t offset; uint32_t pad; };   // texels: RGBA8 at texels[offset + y*w + x]
+template <typename real> struct Key { real t0, t1, a, b; int32_t channel, interp; };
+
+// Camera in `real`.  The four scalars are computed in f64 at set-up as fix_viewport does
+// (rendering_compute.rs:5-11,71-73) and rounded once; everything per-sample is `real`.
+template <typename real> struct CamConst {
+    int32_t W, H;
+    real viewport_width, viewport_height, focus_dist, defocus_radius;
+    int32_t defocus_on, animated;
+    V3<real> from, at, vup;
+    int32_t from_key_first, from_key_count, at_key_first, at_key_count;
+    // static camera: the per-sample vectors, precomputed with the same expression tree
+    V3<real> p00, pdu, pdv, ddu, ddv;
+};
+
+template <typename real> struct KernelArgs {
+    const Entry<real>* entries;
+    const Prim<real>* prims;
+    const Mat<real>* mats;
+    const Tex<real>* texs;
+    const ImageRef* images;
+    const uint32_t* texels;
+    const Key<real>* keys;
+    int32_t n_entries, n_prims, n_mats, n_texs;
+    int32_t sky_kind, sky_image;
+    CamConst<real> cam;
+    int32_t sample_begin, sample_end, samples_total, max_depth;
+    uint64_t seed_mixed;      // mix64(seed + GAMMA)
+    real current_time, shutter_length;
+    int32_t output_sum;
+    uint32_t tiles_x, tiles_y;
+    uint32_t* work_counter;   // zeroed before launch
+    uint64_t* counters;       // [0] segments [1] node tests [2] prim tests [3] texel fetches
+    real* att_stack;          // 3 planes of max_depth * n_threads
+    uint32_t n_threads;
+    real* out;
+};
+
+// ------------------------------------------------------------------ timeline (timeline/mod.rs:233-263)
+template <typename real> CR_HD void timeline_eval(const Key<real>* keys, int n, real t, real& x, real& y, real& z, real& w) {
+    x = real(0) + x; y = real(0) + y; z = real(0) + z;   // identity * initial translate
+    for (int i = 0; i < n; i++) {
+        Key<real> k = keys[i];
+        bool active = (t > k.t1) || (k.t0 <= t && t <= k.t1);   // is_less(t) || contains(t)
+        if (!active) continue;
+        real s = clamp01((t - k.t0) / (k.t1 - k.t0));
+        if (k.channel <= 2) {
+            real val = k.interp ? k.a * s : k.a;
+            if (k.channel == 0) x = x + val; else if (k.channel == 1) y = y + val; else z = z + val;
+        } else if (k.channel == 3) {
+            w = k.interp ? k.a + (k.b - k.a) * s : k.a;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ camera (rendering_compute.rs)
+template <typename real> struct CamFrame { V3<real> from, p00, pdu, pdv, ddu, ddv; };
+
+template <typename real> CR_HD CamFrame<real> camera_frame(const CamConst<real>& c, V3<real> from, V3<real> at) {
+    CamFrame<real> f;
+    f.from = from;
+    V3<real> w = unit(sub(from, at));                           // w_basis :91-96
+    V3<real> u = unit(cross(c.vup, w));                         // u_basis :81-83
+    V3<real> v = cross(w, u);                                   // v_basis :86-88
+    V3<real> vu = scale(c.viewport_width, u);                   // viewport_u :18-20
+    V3<real> vv = scale(c.viewport_height, neg(v));             // viewport_v :25-28
+    f.pdu = divs(vu, (real)c.W);                                // pixel_delta_u :34-36
+    f.pdv = divs(vv, (real)c.H);                                // pixel_delta_v :42-44
+    V3<real> ul = sub(from, scale(c.focus_dist, w));            // viewport_upperleft :51-56
+    ul = sub(ul, divs(vu, real(2)));
+    ul = sub(ul, divs(vv, real(2)));
+    f.p00 = add(ul, scale(real(0.5), add(f.pdu, f.pdv)));       // pixel_start_location :59-61
+    f.ddu = scale(c.defocus_radius, u);                         // defocus_disk_u :99-101
+    f.ddv = scale(c.defocus_radius, v);                         // defocus_disk_v :104-106
+    return f;
+}
+
+#if defined(__HIPCC__)
+// ================================================================== device only
+
+template <typename real> struct Hit {
+    real t;
+    int32_t prim;     // leaf-order index, -1 = miss
+};
+
+// Aabb::hit (bvh.rs:96-132) with 1/dir hoisted (same value every node).  The per-axis
+// early return is folded into one final test: once max <= min holds it keeps holding,
+// because new_min >= min and new_max <= max for non-NaN min/max.
+template <typename real>
+CR_D bool box_hit(const real* b, V3<real> o, V3<real> inv, real tmin, real tmax) {
+    real t0 = (b[0] - o.x) * inv.x, t1 = (b[1] - o.x) * inv.x;
+    real nmin, nmax;
+    if (t0 < t1) { nmin = t0 > tmin ? t0 : tmin; nmax = t1 < tmax ? t1 : tmax; }
+    else { nmin = t1 > tmin ? t1 : tmin; nmax = t0 < tmax ? t0 : tmax; }
+    tmin = nmin; tmax = nmax;
+    t0 = (b[2] - o.y) * inv.y; t1 = (b[3] - o.y) * inv.y;
+    if (t0 < t1) { nmin = t0 > tmin ? t0 : tmin; nmax = t1 < tmax ? t1 : tmax; }
+    else { nmin = t1 > tmin ? t1 : tmin; nmax = t0 < tmax ? t0 : tmax; }
+    tmin = nmin; tmax = nmax;
+    t0 = (b[4] - o.z) * inv.z; t1 = (b[5] - o.z) * inv.z;
+    if (t0 < t1) { nmin = t0 > tmin ? t0 : tmin; nmax = t1 < tmax ? t1 : tmax; }
+    else { nmin = t1 > tmin ? t1 : tmin; nmax = t0 < tmax ? t0 : tmax; }
+    return !(nmax <= nmin);
+}
+
+// Sphere::hit root search (sphere.rs:72-95): returns t or a negative number for a miss.
+template <typename real>
+CR_D bool sphere_t(real cx, real cy, real cz, real radius, V3<real> o, V3<real> d, real tmin, real tmax, real& t_out) {
+    V3<real> oc = sub(mk<real>(cx, cy, cz), o);
+    real a = len2(d);
+    real h = dot(d, oc);
+    real c = len2(oc) - radius * radius;
+    real disc = h * h - a * c;
+    if (disc < real(0)) return false;
+    real sqrtd = r_sqrt(disc);
+    real root = (h - sqrtd) / a;
+    if (!(tmin < root && root < tmax)) {
+        root = (h + sqrtd) / a;
+        if (!(tmin < root && root < tmax)) return false;
+    }
+    t_out = root;
+    return true;
+}
+
+// Triangle::hit up to t (triangle.rs:95-123)
+template <typename real>
+CR_D bool triangle_t(V3<real> a, V3<real> b, V3<real> c, V3<real> o, V3<real> d, real tmin, real tmax, real& t_out) {
+    V3<real> e1 = sub(b, a), e2 = sub(c, a);
+    V3<real> rce2 = cross(d, e2);
+    real det = dot(e1, rce2);
+    if (det > -RealTraits<real>::eps && det < RealTraits<real>::eps) return false;
+    real inv_det = real(1) / det;
+    V3<real> s = sub(o, a);
+    real u = inv_det * dot(s, rce2);
+    if (!(real(0) <= u && u <= real(1))) return false;
+    V3<real> sce1 = cross(s, e1);
+    real v = inv_det * dot(d, sce1);
+    if (v < real(0) || u + v > real(1)) return false;
+    real t = inv_det * dot(e2, sce1);
+    if (!(tmin < t && t < tmax)) return false;
+    t_out = t;
+    return true;
+}
+
+template <typename real> CR_D int32_t as_i32(real x) {   // Rust `as i32`: saturating, NaN -> 0
+    if (!(x == x)) return 0;
+    if (x <= real(-2147483648.0)) return INT32_MIN;
+    if (x >= real(2147483647.0)) return INT32_MAX;
+    return (int32_t)x;
+}
+template <typename real> CR_D uint32_t as_index(real x, int32_t n) {   // `as usize` then clamp to n-1 (img_loader.rs:72-73)
+    if (!(x == x) || x <= real(0)) return 0;
+    if (x >= (real)n) return (uint32_t)(n - 1);
+    return (uint32_t)x;
+}
+
+template <typename real>
+CR_D V3<real> image_lookup(const ImageRef* images, const uint32_t* texels, int image, real u, real v, uint32_t& n_texel) {
+    ImageRef im = images[image];
+    u = clamp01(u);
+    v = real(1) - clamp01(v);
+    uint32_t i = as_index(u * (real)im.w, im.w);
+    uint32_t j = as_index(v * (real)im.h, im.h);
+    uint32_t px = texels[im.offset + j * (uint32_t)im.w + i];
+    n_texel++;
+    return mk<real>((real)(px & 255u) / real(255), (real)((px >> 8) & 255u) / real(255), (real)((px >> 16) & 255u) / real(255));
+}
+
+// device math the sky / sphere-uv lookups need (ocml); kept in one place
+CR_D float r_atan2(float y, float x) { return atan2f(y, x); }
+CR_D double r_atan2(double y, double x) { return atan2(y, x); }
+CR_D float r_asin(float x) { return asinf(x); }
+CR_D double r_asin(double x) { return asin(x); }
+CR_D float r_acos(float x) { return acosf(x); }
+CR_D double r_acos(double x) { return acos(x); }
+
+enum : int { ST_NEED_PIXEL = 0, ST_NEED_SAMPLE = 1, ST_TRACE = 2, ST_DONE = 3 };
+
+constexpr int kBlock = 256;
+
+// One lane = one pixel at a time, all of that pixel's samples in draw order (so the
+// per-pixel sum is the reference's sequential sum).  Lanes that finish a pixel pull the
+// next pixel index with one wave-aggregated atomic (ballot + prefix count).
+template <typename real, bool LDS_SCENE, bool ANIM>
+__global__ void __launch_bounds__(kBlock) pathtrace_kernel(const KernelArgs<real> A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Entry<real>* entries = A.entries;
+    const Prim<real>* prims = A.prims;
+    const Mat<real>* mats = A.mats;
+    const Tex<real>* texs = A.texs;
+    if (LDS_SCENE) {
+        // stage the whole scene: entries | prims | mats | texs, each 16-B aligned
+        size_t o0 = 0;
+        size_t o1 = o0 + (((size_t)A.n_entries * sizeof(Entry<real>) + 15) & ~(size_t)15);
+        size_t o2 = o1 + (((size_t)A.n_prims * sizeof(Prim<real>) + 15) & ~(size_t)15);
+        size_t o3 = o2 + (((size_t)A.n_mats * sizeof(Mat<real>) + 15) & ~(size_t)15);
+        size_t o4 = o3 + (((size_t)A.n_texs * sizeof(Tex<real>) + 15) & ~(size_t)15);
+        auto copy = [&](const void* src, size_t off, size_t bytes) {
+            const uint32_t* s = (const uint32_t*)src;
+            uint32_t* d = (uint32_t*)(smem + off);
+            for (size_t i = threadIdx.x; i < bytes / 4; i += blockDim.x) d[i] = s[i];
+        };
+        copy(A.entries, o0, (size_t)A.n_entries * sizeof(Entry<real>));
+        copy(A.prims, o1, (size_t)A.n_prims * sizeof(Prim<real>));
+        copy(A.mats, o2, (size_t)A.n_mats * sizeof(Mat<real>));
+        copy(A.texs, o3, (size_t)A.n_texs * sizeof(Tex<real>));
+        (void)o4;
+        __syncthreads();
+        entries = (const Entry<real>*)(smem + o0);
+        prims = (const Prim<real>*)(smem + o1);
+        mats = (const Mat<real>*)(smem + o2);
+        texs = (const Tex<real>*)(smem + o3);
+    }
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total_work = A.tiles_x * A.tiles_y * 64u;
+    const CamConst<real>& cam = A.cam;
+
+    int state = ST_NEED_PIXEL;
+    uint32_t pix_i = 0, pix_j = 0;
+    int32_t sample = 0;
+    real acc_r = 0, acc_g = 0, acc_b = 0;
+    // path state
+    V3<real> ro = mk<real>(0, 0, 0), rd = mk<real>(0, 0, 1);
+    real rtime = 0;
+    uint64_t rng = 0;
+    int32_t depth_left = 0, stack_n = 0;
+    uint32_t c_seg = 0, c_prim = 0, c_tex = 0;
+    unsigned long long c_node = 0;
+
+    for (;;) {
+        // ---------------- regeneration: pixels
+        uint64_t need = __ballot(state == ST_NEED_PIXEL);
+        if (need) {
+            uint32_t cnt = (uint32_t)__popcll(need);
+            uint32_t base = 0;
+            int leader = __ffsll((unsigned long long)need) - 1;
+            if ((int)lane == leader) base = atomicAdd(A.work_counter, cnt);
+            base = __shfl(base, leader);
+            if (state == ST_NEED_PIXEL) {
+                uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                uint32_t w = base + rank;
+                if (w >= total_work) state = ST_DONE;
+                else {
+                    uint32_t tile = w >> 6, in = w & 63u;
+                    pix_i = (tile % A.tiles_x) * 8u + (in & 7u);
+                    pix_j = (tile / A.tiles_x) * 8u + (in >> 3);
+                    if (pix_i < (uint32_t)cam.W && pix_j < (uint32_t)cam.H) {
+                        state = ST_NEED_SAMPLE; sample = A.sample_begin; acc_r = acc_g = acc_b = 0;
+                    }   // else: padding of an edge tile, ask again next round
+                }
+            }
+        }
+        if (__ballot(state != ST_DONE) == 0) break;
+
+        // ---------------- regeneration: camera rays (cast_ray, ray_casting.rs:82-105)
+        if (state == ST_NEED_SAMPLE) {
+            uint32_t pixel = pix_j * (uint32_t)cam.W + pix_i;
+            rng = rng_key(A.seed_mixed, pixel, (uint32_t)sample);
+            real ts = A.current_time + rng_range<real>(rng, real(0), A.shutter_length);
+            real ox = rng_uniform<real>(rng) - real(0.5);   // sample_square, camera/mod.rs:368-376
+            real oy = rng_uniform<real>(rng) - real(0.5);
+            CamFrame<real> f;
+            if (ANIM && cam.animated) {
+                real fx = cam.from.x, fy = cam.from.y, fz = cam.from.z, fw = real(1);
+                real ax = cam.at.x, ay = cam.at.y, az = cam.at.z, aw = real(1);
+                timeline_eval(A.keys + cam.from_key_first, cam.from_key_count, ts, fx, fy, fz, fw);
+                timeline_eval(A.keys + cam.at_key_first, cam.at_key_count, ts, ax, ay, az, aw);
+                f = camera_frame(cam, mk<real>(fw * fx, fw * fy, fw * fz), mk<real>(aw * ax, aw * ay, aw * az));
+            } else {
+                f.from = cam.from; f.p00 = cam.p00; f.pdu = cam.pdu; f.pdv = cam.pdv; f.ddu = cam.ddu; f.ddv = cam.ddv;
+            }
+            V3<real> ps = add(add(f.p00, scale((real)pix_i + ox, f.pdu)), scale((real)pix_j + oy, f.pdv));   // get_pixel_pos :64-68
+            V3<real> orig = f.from;
+            if (cam.defocus_on) {   // defocus_disk_sample :104-110, random_in_unit_disk utils.rs:110-124
+                real px, py;
+                for (;;) {
+                    px = rng_range<real>(rng, real(-1), real(1));
+                    py = rng_range<real>(rng, real(-1), real(1));
+                    if (px * px + py * py + real(0) * real(0) < real(1)) break;
+                }
+                orig = add(add(f.from, scale(px, f.ddu)), scale(py, f.ddv));
+            }
+            ro = orig; rd = sub(ps, orig); rtime = ts;
+            depth_left = A.max_depth; stack_n = 0;
+            state = ST_TRACE;
+        }
+
+        // ---------------- closest hit (Hittables::hit on the BVH root, interval (0.001, inf))
+        bool tracing = (state == ST_TRACE);
+        V3<real> col = mk<real>(0, 0, 0);   // colour returned by the innermost ray_color call
+        bool finished = false;
+        if (tracing && depth_left == 0) { finished = true; tracing = false; }   // ray_color: depth == 0 -> black
+        real best_t = r_inf(real(0));
+        int32_t best = -1;
+        if (tracing) {
+            c_seg++;
+            const real tmin = real(0.001);
+            V3<real> inv = mk<real>(real(1) / rd.x, real(1) / rd.y, real(1) / rd.z);
+            int32_t idx = 0;
+            const int32_t n_entries = A.n_entries;
+            while (idx < n_entries) {
+                const Entry<real> e = entries[idx];
+                c_node++;
+                bool hit = box_hit(e.b, ro, inv, tmin, best_t);
+                int32_t next = hit ? idx + 1 : e.skip;
+                if (hit && e.leaf >= 0) {
+                    int32_t first = e.leaf >> 1, count = (e.leaf & 1) + 1;
+                    for (int32_t k = 0; k < count; k++) {
+                        const Prim<real>& p = prims[first + k];
+                        c_prim++;
+                        real t;
+                        bool h;
+                        real g0 = p.g[0], g1 = p.g[1], g2 = p.g[2], g3 = p.g[3];
+                        if (p.kind() == 0) {
+                            if (ANIM && p.key_count) timeline_eval(A.keys + p.key_first, p.key_count, rtime, g0, g1, g2, g3);
+                            h = sphere_t(g0, g1, g2, g3, ro, rd, tmin, best_t, t);
+                        } else {
+                            V3<real> a = mk<real>(g0, g1, g2), b = mk<real>(g3, p.g[4], p.g[5]), c = mk<real>(p.g[6], p.g[7], p.g[8]);
+                            if (ANIM && p.key_count) {
+                                real w = real(1);
+                                timeline_eval(A.keys + p.key_first, p.key_count, rtime, a.x, a.y, a.z, w); a = scale(w, a); w = real(1);
+                                timeline_eval(A.keys + p.key_first, p.key_count, rtime, b.x, b.y, b.z, w); b = scale(w, b); w = real(1);
+                                timeline_eval(A.keys + p.key_first, p.key_count, rtime, c.x, c.y, c.z, w); c = scale(w, c);
+                            }
+                            h = triangle_t(a, b, c, ro, rd, tmin, best_t, t);
+                        }
+                        if (h) { best_t = t; best = first + k; }
+                    }
+                }
+                idx = next;
+            }
+        }
+
+        // ---------------- shade
+        if (tracing) {
+            if (best >= 0) {
+                const Prim<real>& p = prims[best];
+                V3<real> loc = add(ro, scale(best_t, rd));   // Ray::at
+                V3<real> n;
+                real tu = 0, tv = 0;
+                const Mat<real> m = mats[p.mat()];
+                bool need_uv = false;
+                int32_t leaf_tex = -1;
+                if (m.kind == 0 && m.tex >= 0) {   // only image textures read u,v
+                    int ti = m.tex;
+                    for (int guard = 0; guard < 32 && texs[ti].kind == 1; guard++) {   // checker_texture.rs:38-51
+                        const Tex<real>& tx = texs[ti];
+                        int32_t s = (int32_t)((uint32_t)as_i32(r_floor(tx.inv_scale * loc.x)) + (uint32_t)as_i32(r_floor(tx.inv_scale * loc.y)) +
+                                              (uint32_t)as_i32(r_floor(tx.inv_scale * loc.z)));
+                        ti = (s % 2 == 0) ? tx.even : tx.odd;
+                    }
+                    need_uv = texs[ti].kind == 2;
+                    leaf_tex = ti;
+                }
+                if (p.kind() == 0) {
+                    real g0 = p.g[0], g1 = p.g[1], g2 = p.g[2], g3 = p.g[3];
+                    if (ANIM && p.key_count) timeline_eval(A.keys + p.key_first, p.key_count, rtime, g0, g1, g2, g3);
+                    n = divs(sub(loc, mk<real>(g0, g1, g2)), g3);   // sphere.rs:97
+                    if (need_uv) {                                  // get_sphere_uv, sphere.rs:41-46
+                        real theta = r_acos(-n.y);
+                        real phi = r_atan2(-n.z, n.x) + RealTraits<real>::pi;
+                        tu = phi / (real(2) * RealTraits<real>::pi);
+                        tv = theta / RealTraits<real>::pi;
+                    }
+                } else {
+                    V3<real> a = mk<real>(p.g[0], p.g[1], p.g[2]), b = mk<real>(p.g[3], p.g[4], p.g[5]), c = mk<real>(p.g[6], p.g[7], p.g[8]);
+                    if (ANIM && p.key_count) {
+                        real w = real(1);
+                        timeline_eval(A.keys + p.key_first, p.key_count, rtime, a.x, a.y, a.z, w); a = scale(w, a); w = real(1);
+                        timeline_eval(A.keys + p.key_first, p.key_count, rtime, b.x, b.y, b.z, w); b = scale(w, b); w = real(1);
+                        timeline_eval(A.keys + p.key_first, p.key_count, rtime, c.x, c.y, c.z, w); c = scale(w, c);
+                    }
+                    n = unit(cross(sub(b, a), sub(c, a)));          // safe_new, objects/mod.rs:76
+                    tu = 0; tv = 0;                                 // triangle.rs:130-131
+                }
+                bool front = dot(rd, n) < real(0);                  // HitRecord::new
+                if (!front) n = neg(n);
+
+                V3<real> att = mk<real>(0, 0, 0), ndir = rd;
+                bool some;
+                if (m.kind == 0) {                                  // lambertian.rs:40-61
+                    V3<real> dir = add(n, random_unit_vector<real>(rng));
+                    real tol = real(1e-8);
+                    if (r_abs(dir.x) < tol && r_abs(dir.y) < tol && r_abs(dir.z) < tol) dir = n;
+                    V3<real> tc;
+                    if (m.tex < 0) tc = mk<real>(m.albedo[0], m.albedo[1], m.albedo[2]);
+                    else if (need_uv) tc = image_lookup(A.images, A.texels, texs[leaf_tex].image, tu, tv, c_tex);
+                    else tc = mk<real>(texs[leaf_tex].color[0], texs[leaf_tex].color[1], texs[leaf_tex].color[2]);
+                    att = c_div(tc, m.param);
+                    ndir = dir;
+                    some = rng_uniform<real>(rng) <= m.param;
+                } else if (m.kind == 1) {                           // metal.rs:29-42
+                    V3<real> refl = reflect(rd, n);
+                    refl = add(unit(refl), scale(m.param, random_unit_vector<real>(rng)));
+                    att = mk<real>(m.albedo[0], m.albedo[1], m.albedo[2]);
+                    ndir = refl;
+                    some = dot(refl, n) > real(0);
+                } else {                                            // dielectric.rs:30-55
+                    att = mk<real>(1, 1, 1);
+                    real ri = front ? real(1) / m.param : m.param;
+                    V3<real> ud = unit(rd);
+                    real cos_theta = -(r_fmin(dot(ud, n), real(1)));
+                    real sin_theta = r_sqrt(real(1) - cos_theta * cos_theta);
+                    bool refl = ri * sin_theta > real(1);
+                    if (!refl) {
+                        real r0 = (real(1) - ri) / (real(1) + ri);
+                        r0 = r0 * r0;
+                        real x = real(1) - cos_theta;
+                        real x2 = x * x;
+                        real x5 = x * (x2 * x2);
+                        refl = (r0 + (real(1) - r0) * x5) > rng_uniform<real>(rng);
+                    }
+                    ndir = refl ? reflect(ud, n) : refract(ud, n, ri);
+                    some = true;
+                }
+                if (some) {
+                    // attenuation * ray_color(scattered): the product is formed innermost-first,
+                    // so remember the factor and multiply on the way back (ray_casting.rs:128).
+                    // (1,1,1) multiplies exactly and need not be stored.
+                    if (m.kind != 2) {
+                        size_t plane = (size_t)A.max_depth * A.n_threads;
+                        size_t at = (size_t)stack_n * A.n_threads + gtid;
+                        A.att_stack[at] = att.x; A.att_stack[plane + at] = att.y; A.att_stack[2 * plane + at] = att.z;
+                        stack_n++;
+                    }
+                    ro = loc; rd = ndir; depth_left--;
+                } else {
+                    finished = true;                                // scatter None -> black
+                }
+            } else {
+                // sky (ray_casting.rs:133-151)
+                V3<real> ud = unit(rd);
+                if (A.sky_kind == 1) {
+                    real theta = r_atan2(ud.x, ud.z);
+                    real phi = r_asin(ud.y);
+                    real u = (theta / (real(2) * RealTraits<real>::pi)) + real(0.5);
+                    real v = (phi / RealTraits<real>::pi) + real(0.5);
+                    col = image_lookup(A.images, A.texels, A.sky_image, u, v, c_tex);
+                } else {
+                    real a = real(0.5) * (ud.y + real(1));
+                    col = c_add(c_scale(real(1) - a, mk<real>(1, 1, 1)), c_scale(a, mk<real>(real(0.5), real(0.7), real(1))));
+                }
+                // unwind: a_1 * (a_2 * ( ... (a_n * sky)))
+                size_t plane = (size_t)A.max_depth * A.n_threads;
+                for (int32_t k = stack_n - 1; k >= 0; k--) {
+                    size_t at = (size_t)k * A.n_threads + gtid;
+                    V3<real> a_k = mk<real>(A.att_stack[at], A.att_stack[plane + at], A.att_stack[2 * plane + at]);
+                    col = c_mul(a_k, col);
+                }
+                finished = true;
+            }
+        }
+
+        // ---------------- sample / pixel completion (average_samples, ray_casting.rs:154-173)
+        if (finished) {
+            acc_r += col.x; acc_g += col.y; acc_b += col.z;
+            sample++;
+            if (sample == A.sample_end) {
+                size_t o = ((size_t)pix_j * (size_t)cam.W + pix_i) * 3;
+                if (A.output_sum) { A.out[o] = acc_r; A.out[o + 1] = acc_g; A.out[o + 2] = acc_b; }
+                else {
+                    real cnt = (real)A.samples_total;
+                    A.out[o] = acc_r / cnt; A.out[o + 1] = acc_g / cnt; A.out[o + 2] = acc_b / cnt;
+                }
+                state = ST_NEED_PIXEL;
+            } else state = ST_NEED_SAMPLE;
+        }
+    }
+
+    // flush work counters: one atomic per counter per wave
+    auto wave_sum = [&](unsigned long long v) -> unsigned long long {
+        unsigned long long s = v;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+        return s;
+    };
+    unsigned long long s0 = wave_sum(c_seg), s1 = wave_sum(c_node), s2 = wave_sum(c_prim), s3 = wave_sum(c_tex);
+    if (lane == 0) {
+        atomicAdd((unsigned long long*)&A.counters[0], s0);
+        atomicAdd((unsigned long long*)&A.counters[1], s1);
+        atomicAdd((unsigned long long*)&A.counters[2], s2);
+        atomicAdd((unsigned long long*)&A.counters[3], s3);
+    }
+}
+#endif   // __HIPCC__
+
+}   // namespace cr

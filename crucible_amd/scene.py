@@ -1,0 +1,446 @@
+"""Host-side mirror of Crucible's Scene / Camera builder API, flattened to the C ABI.
+
+Names, argument meaning and error behaviour follow the reference:
+  Scene        src/scene/mod.rs:75-347, src/scene/scene_animator.rs
+  Camera       src/camera/mod.rs:66-263
+  Sphere       src/objects/sphere.rs:25-39      Triangle  src/objects/triangle.rs:23-46
+  Lambertian / Metal / Dielectric   src/materials/{lambertian,metal,dielectric}.rs
+  SolidColor / CheckerTexture / ImageTexture   src/textures/*.rs
+  load_obj     src/asset_loader/obj_loader.rs:21-143
+Where the reference panics this raises; where it returns io::Error the C ABI
+returns CR_ERR_IO.  Nothing here computes pixels: `Scene.flatten()` produces the
+CrSceneDesc / CrCameraDesc the library (or, in tests, the oracle) consumes, and
+`Scene.render_scene()` is Camera::render over the HIP library + the PPM writer.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+from . import _abi as A
+from .timeline import LERP, LOCAL, NERP, WORLD, TransformTimeline  # noqa: F401
+
+
+def _color(c):
+    r, g, b = (float(x) for x in c)
+    # Color::new asserts 0 <= c <= 1 (utils.rs:345-350)
+    for name, v in (("R", r), ("G", g), ("B", b)):
+        if not (0.0 <= v <= 1.0):
+            raise ValueError(f"{name} must be between 0.0 and 1.0. Got {v}")
+    return (r, g, b)
+
+
+# ------------------------------------------------------------------ textures
+class SolidColor:
+    def __init__(self, albedo):
+        self.albedo = _color(albedo)
+
+    new_from_color = classmethod(lambda cls, c: cls(c))
+    new_from_rgb = classmethod(lambda cls, r, g, b: cls((r, g, b)))
+
+
+class CheckerTexture:
+    def __init__(self, scale, even, odd):
+        self.inv_scale = 1.0 / float(scale)   # checker_texture.rs:23,31
+        self.even, self.odd = even, odd
+
+    @classmethod
+    def new_from_textures(cls, scale, even, odd):
+        return cls(scale, even, odd)
+
+    @classmethod
+    def new_from_color(cls, scale, c1, c2):
+        return cls(scale, SolidColor(c1), SolidColor(c2))
+
+
+class RTWImage:
+    """Decoded RGB8 image (img_loader.rs:17-55).  `rgb8` is HxWx3 uint8."""
+
+    def __init__(self, rgb8):
+        arr = np.ascontiguousarray(rgb8, dtype=np.uint8)
+        assert arr.ndim == 3 and arr.shape[2] == 3
+        self.rgb8 = arr
+
+    @classmethod
+    def new(cls, filename):
+        path = build_asset_path(filename)
+        from PIL import Image   # the reference uses the `image` crate; decoders may differ by an LSB
+        with Image.open(path) as im:
+            return cls(np.asarray(im.convert("RGB")))
+
+    def width(self):
+        return self.rgb8.shape[1]
+
+    def height(self):
+        return self.rgb8.shape[0]
+
+
+class ImageTexture:
+    def __init__(self, image):
+        self.image = image if isinstance(image, RTWImage) else RTWImage.new(image)
+
+    new = classmethod(lambda cls, filename: cls(filename))
+
+
+# ------------------------------------------------------------------ materials
+class Lambertian:
+    def __init__(self, tex, prob):
+        self.tex, self.scatter_prob = tex, float(prob)
+
+    @classmethod
+    def new_from_color(cls, c, prob):
+        return cls(SolidColor(c), prob)
+
+    @classmethod
+    def new_from_texture(cls, tex, prob):
+        return cls(tex, prob)
+
+
+class Metal:
+    def __init__(self, c, fuzz):
+        # metal.rs:21-23
+        if fuzz > 1.0:
+            raise ValueError("A metal cannot have a fuzz factor above 1.0")
+        if fuzz < 0.0:
+            raise ValueError("A metal cannot have a fuzz factor below 0.0")
+        self.albedo, self.fuzz = _color(c), float(fuzz)
+
+    new = classmethod(lambda cls, c, fuzz: cls(c, fuzz))
+
+
+class Dielectric:
+    def __init__(self, refraction_index):
+        self.refraction_index = float(refraction_index)
+
+    new = classmethod(lambda cls, ri: cls(ri))
+
+
+# ------------------------------------------------------------------ objects
+class Sphere:
+    def __init__(self, center, radius, mat):
+        if not radius >= 0.0:
+            raise ValueError("Cannot make a sphere with negative radius")   # sphere.rs:26
+        self.id, self.hide = 0, False
+        self.center, self.radius, self.mat = tuple(float(c) for c in center), float(radius), mat
+        self.timeline = TransformTimeline.new_sphere(self.center, self.radius)
+
+    new = classmethod(lambda cls, c, r, m: cls(c, r, m))
+
+
+class Triangle:
+    def __init__(self, a, b, c, mat):
+        self.id, self.hide = 0, False
+        self.a, self.b, self.c = (tuple(float(x) for x in p) for p in (a, b, c))
+        self.mat = mat
+        # a_/b_/c_timeline only ever receive the same calls (scene_animator.rs); one is kept
+        self.timeline = TransformTimeline(self.a)
+
+    new = classmethod(lambda cls, a, b, c, m: cls(a, b, c, m))
+
+
+def build_asset_path(asset_filename):
+    """asset_loader/mod.rs:6-41: $ASSET_DIR is prepended verbatim; else `assets/` up to six levels up."""
+    folder = os.environ.get("ASSET_DIR")
+    if folder is not None:
+        return folder + asset_filename
+    here = os.path.dirname(os.path.abspath(__file__))
+    for base in ("", "..", "../..", "../../..", "../../../..", "../../../../..", "../../../../../.."):
+        p = os.path.join(base, "assets", asset_filename)
+        if os.path.exists(p):
+            return p
+    p = os.path.join(here, "..", "assets", asset_filename)   # repo checkout
+    if os.path.exists(p):
+        return p
+    raise FileNotFoundError("Could not find the asset " + asset_filename)
+
+
+def load_obj(file, scale, shift, mat):
+    """obj_loader.rs:21-143: `v`/`f` lines only, 1-based, triangles only, scale*p + shift."""
+    path = build_asset_path(file)
+    if not path.endswith(".obj"):
+        raise ValueError("Expected an obj file.")
+    verts, faces = [], []
+    with open(path) as fh:
+        for line in fh:
+            parts = line.split()
+            if not parts:
+                continue
+            if parts[0] == "v":
+                if len(parts) != 4:
+                    raise ValueError("Invalid number of coordinates for a vertex")
+                verts.append(tuple(float(x) for x in parts[1:]))
+            elif parts[0] == "f":
+                if len(parts) != 4:
+                    raise ValueError("The asset loader only supports triangularized images")
+                faces.append(tuple(int(x) for x in parts[1:]))
+            else:
+                raise ValueError("Unsupported OBJ file")
+    verts = [tuple(scale * p[k] + shift[k] for k in range(3)) for p in verts]
+    return [Triangle(verts[f[0] - 1], verts[f[1] - 1], verts[f[2] - 1], mat) for f in faces]
+
+
+# ------------------------------------------------------------------ camera
+class Camera:
+    """Camera::new + setters (camera/mod.rs:106-263)."""
+
+    def __init__(self, aspect_ratio, image_width, frame_rate, shutter_angle, thread_count):
+        self.aspect_ratio = float(aspect_ratio)
+        self.image_width = int(image_width)
+        self.image_height = max(1, int(self.image_width / self.aspect_ratio))   # Viewport::new :37-38
+        self.vfov_degrees = 90.0
+        self.look_from_tl = TransformTimeline((0.0, 0.0, 0.0))
+        self.look_at_tl = TransformTimeline((0.0, 0.0, 0.0))
+        self.vup = (0.0, 1.0, 0.0)
+        self.defocus_angle_degrees = 0.0
+        self.focus_dist = 10.0
+        self.samples, self.max_depth = 10, 10
+        self.thread_count = thread_count
+        self.frame_rate, self.frame, self.shutter_angle = float(frame_rate), 0, float(shutter_angle)
+
+    def next_frame(self):
+        self.frame += 1
+
+    def look_from(self, loc):
+        self.look_from_tl = TransformTimeline(loc)
+
+    def look_at(self, loc):
+        self.look_at_tl = TransformTimeline(loc)
+
+    def set_vup(self, vup):
+        self.vup = tuple(float(x) for x in vup)
+
+    def set_vfov(self, vfov_degrees):
+        self.vfov_degrees = float(vfov_degrees)
+
+    def set_hfov(self, hfov_degrees):   # camera/mod.rs:220-228
+        hfov = hfov_degrees * math.pi / 180.0
+        self.set_vfov((math.atan(math.tan(hfov / (2.0 * self.aspect_ratio))) * 2.0) * 180.0 / math.pi)
+
+    def set_samples(self, s):
+        if not s > 0:
+            raise ValueError(f"The camera must have a positive number of samples. {s} is invalid.")
+        self.samples = int(s)
+
+    def set_max_depth(self, md):
+        self.max_depth = int(md)
+
+    def set_defocus_angle(self, da_degree):
+        self.defocus_angle_degrees = float(da_degree)
+
+    def set_focus_dist(self, fd):
+        self.focus_dist = float(fd)
+
+    def set_threads(self, threads):
+        self.thread_count = threads
+
+    def desc(self):
+        fk, ak = self.look_from_tl.keyframes(), self.look_at_tl.keyframes()
+        fa = (A.CrKeyframe * max(1, len(fk)))(*fk)
+        aa = (A.CrKeyframe * max(1, len(ak)))(*ak)
+        d = A.CrCameraDesc(self.image_width, self.image_height, self.vfov_degrees, self.defocus_angle_degrees,
+                           self.focus_dist, (C.c_double * 3)(*self.look_from_tl.start_pos),
+                           (C.c_double * 3)(*self.look_at_tl.start_pos), (C.c_double * 3)(*self.vup),
+                           len(fk), len(ak), fa, aa)
+        d._keep = (fa, aa)
+        return d
+
+    def params(self, seed, real_type, sample_begin=0, sample_count=None, output_sum=False):
+        n = self.samples if sample_count is None else sample_count
+        return A.CrRenderParams(self.samples, sample_begin, n, self.max_depth, seed, self.frame, real_type,
+                                self.frame_rate, self.shutter_angle, 1 if output_sum else 0, 0)
+
+
+# ------------------------------------------------------------------ scene
+class FlatScene:
+    """CrSceneDesc plus the buffers it points into."""
+
+    def __init__(self, prims, materials, textures, images, keys, sky_kind, sky_image):
+        self.prims = (A.CrPrimitive * max(1, len(prims)))(*prims)
+        self.materials = (A.CrMaterial * max(1, len(materials)))(*materials)
+        self.textures = (A.CrTexture * max(1, len(textures)))(*textures)
+        self._image_arrays = images
+        imgs = [A.CrImage(im.shape[1], im.shape[0], im.ctypes.data_as(C.POINTER(C.c_uint8))) for im in images]
+        self.images = (A.CrImage * max(1, len(imgs)))(*imgs)
+        self.keys = (A.CrKeyframe * max(1, len(keys)))(*keys)
+        self.desc = A.CrSceneDesc(len(prims), len(materials), len(textures), len(images), len(keys), sky_kind,
+                                  sky_image, 0, self.prims, self.materials, self.textures, self.images, self.keys)
+
+
+class Scene:
+    def __init__(self, aspect_ratio, image_width, frame_rate, shutter_angle, thread_count, duration=None):
+        self.scene_cam = Camera(aspect_ratio, image_width, float(frame_rate), shutter_angle, thread_count)
+        self.elements = []
+        self.skybox = None          # Skybox::Default
+        self._aliases = {"cam": (0, "Camera")}   # id_vendor.rs: "cam" reserved as id 0
+        self._next_id = 1
+        self.duration = duration
+        self.frame_rate = int(frame_rate)
+        self.seed = 0xC0FFEE
+        self.real_type = A.CR_REAL_F32
+        self.device = 0
+
+    @classmethod
+    def new_image(cls, aspect_ratio, image_width, frame_rate, shutter_angle, thread_count):
+        return cls(aspect_ratio, image_width, frame_rate, shutter_angle, thread_count)
+
+    @classmethod
+    def new_movie(cls, aspect_ratio, image_width, frame_rate, shutter_angle, thread_count, duration):
+        return cls(aspect_ratio, image_width, frame_rate, shutter_angle, thread_count, duration)
+
+    def _vend_id(self, alias, otype):
+        if alias in self._aliases:
+            raise ValueError(f"This {otype}'s alias collides with another name in the scene! Try changing {alias} to a new name.")
+        self._aliases[alias] = (self._next_id, otype)
+        self._next_id += 1
+        return self._aliases[alias][0]
+
+    def load_default_skybox(self):
+        self.skybox = None
+
+    def load_spherical_skybox(self, file):
+        self.skybox = file if isinstance(file, RTWImage) else RTWImage.new(file)
+
+    def add_element(self, element, alias):
+        element.id = self._vend_id(alias, "Sphere" if isinstance(element, Sphere) else "Triangle")
+        self.elements.append(element)
+
+    def load_asset(self, asset_path, alias, scale, shift, mat):
+        mesh_id = self._vend_id(alias, "TriangleMesh")
+        for t in load_obj(asset_path, scale, shift, mat):
+            t.id = mesh_id
+            self.elements.append(t)
+
+    def _lookup(self, alias, invalid=()):
+        if alias not in self._aliases:
+            raise KeyError(f"Could not find an object with the alias: `{alias}`. Are you sure you spelled it right?")
+        oid, otype = self._aliases[alias]
+        if otype in invalid:
+            raise ValueError(f"this transform cannot apply to a {otype}")
+        return oid
+
+    def show_element(self, alias):
+        self._set_visibility(alias, False)
+
+    def hide_element(self, alias):
+        self._set_visibility(alias, True)
+
+    def _set_visibility(self, alias, hide):
+        if alias not in self._aliases:
+            print(f"WARNING: The element `{alias}` does not exist. Are you sure you typed the right name?")
+            return
+        oid = self._aliases[alias][0]
+        for e in self.elements:
+            if e.id == oid:
+                e.hide = hide
+
+    # scene_animator.rs
+    def translate_point(self, p, keyframe, it, space, alias):
+        oid = self._lookup(alias, invalid=("Camera",))
+        for e in self.elements:
+            if e.id == oid:
+                e.timeline.translate_point(p, keyframe, it, space)
+
+    def scale_r(self, r, keyframe, it, alias):
+        oid = self._lookup(alias, invalid=("Camera", "TriangleMesh", "Triangle"))   # scene_animator.rs:140-150
+        for e in self.elements:
+            if e.id == oid:
+                e.timeline.scale_sphere(r, keyframe, it)
+
+    def cam_translate_point(self, p, keyframe, it, space, which):
+        tl = self.scene_cam.look_from_tl if which == "from" else self.scene_cam.look_at_tl
+        tl.translate_point(p, keyframe, it, space)
+
+    # ---- flatten to the C ABI
+    def flatten(self):
+        materials, textures, images, keys, prims = [], [], [], [], []
+        tex_ids, mat_ids, img_ids = {}, {}, {}
+
+        def image_id(img):
+            if id(img) not in img_ids:
+                img_ids[id(img)] = len(images)
+                images.append(img.rgb8)
+            return img_ids[id(img)]
+
+        def texture_id(t):
+            if id(t) in tex_ids:
+                return tex_ids[id(t)]
+            if isinstance(t, SolidColor):
+                rec = A.CrTexture(A.CR_TEX_SOLID, -1, -1, -1, (C.c_double * 3)(*t.albedo), 0.0)
+            elif isinstance(t, CheckerTexture):
+                e, o = texture_id(t.even), texture_id(t.odd)
+                rec = A.CrTexture(A.CR_TEX_CHECKER, e, o, -1, (C.c_double * 3)(0, 0, 0), t.inv_scale)
+            else:
+                rec = A.CrTexture(A.CR_TEX_IMAGE, -1, -1, image_id(t.image), (C.c_double * 3)(0, 0, 0), 0.0)
+            tex_ids[id(t)] = len(textures)
+            textures.append(rec)
+            return tex_ids[id(t)]
+
+        def material_id(m):
+            if id(m) in mat_ids:
+                return mat_ids[id(m)]
+            if isinstance(m, Lambertian):
+                rec = A.CrMaterial(A.CR_MAT_LAMBERTIAN, texture_id(m.tex), (C.c_double * 3)(0, 0, 0), m.scatter_prob)
+            elif isinstance(m, Metal):
+                rec = A.CrMaterial(A.CR_MAT_METAL, -1, (C.c_double * 3)(*m.albedo), m.fuzz)
+            else:
+                rec = A.CrMaterial(A.CR_MAT_DIELECTRIC, -1, (C.c_double * 3)(1, 1, 1), m.refraction_index)
+            mat_ids[id(m)] = len(materials)
+            materials.append(rec)
+            return mat_ids[id(m)]
+
+        for e in self.elements:
+            ks = e.timeline.keyframes()
+            v = (C.c_double * 9)()
+            if isinstance(e, Sphere):
+                v[0:4] = [*e.center, e.radius]
+                kind = A.CR_PRIM_SPHERE
+            else:
+                v[0:9] = [*e.a, *e.b, *e.c]
+                kind = A.CR_PRIM_TRIANGLE
+            prims.append(A.CrPrimitive(kind, material_id(e.mat), A.CR_PRIM_HIDDEN if e.hide else 0, len(keys),
+                                       len(ks), 0, v))
+            keys.extend(ks)
+        sky_kind, sky_image = A.CR_SKY_DEFAULT, -1
+        if self.skybox is not None:
+            sky_kind, sky_image = A.CR_SKY_SPHERICAL, image_id(self.skybox)
+        return FlatScene(prims, materials, textures, images, keys, sky_kind, sky_image)
+
+    # ---- Camera::render over the HIP library (scene/mod.rs:283-347)
+    def compute_frame_count(self):
+        return int(math.ceil(self.duration * self.frame_rate))   # scene/mod.rs:324-330
+
+    def render_scene(self, fname):
+        if self.duration is not None:
+            return self.render_movie(fname)
+        return self.render_image(fname)
+
+    def render_image(self, fname, renderer=None):
+        from .renderer import Renderer
+        own = renderer is None
+        r = renderer or Renderer(self.device)
+        try:
+            r.upload_scene(self.flatten())
+            img, stats = r.render(self.scene_cam, seed=self.seed, real_type=self.real_type)
+            r.write_ppm(fname + ".ppm", img)
+            print(f"Successful render! Image stored at: {fname}.ppm")
+            return stats
+        finally:
+            if own:
+                r.close()
+
+    def render_movie(self, fname):
+        from .renderer import Renderer
+        os.mkdir(fname)   # scene/mod.rs:296: fails if it exists
+        os.mkdir(os.path.join(fname, "artifacts"))
+        frames = self.compute_frame_count()
+        digits = len(str(frames))
+        r = Renderer(self.device)
+        try:
+            r.upload_scene(self.flatten())
+            for frame in range(frames):
+                img, _ = r.render(self.scene_cam, seed=self.seed, real_type=self.real_type)
+                r.write_ppm(os.path.join(fname, "artifacts", f"image{frame:0{digits}d}.ppm"), img)
+                self.scene_cam.next_frame()
+        finally:
+            r.close()

@@ -1,0 +1,273 @@
+/*
+ * crucible_hip.h -- C ABI of the MI355X (gfx950) path-tracing integrator that
+ * stands in for Crucible's per-pixel render loop.
+ *
+ * The reference (kylittle/Crucible, Rust) has no FFI.  The seam this ABI
+ * replaces is
+ *
+ *     pub fn Camera::render(&mut self, skybox: &Skybox, world: &Hittables,
+ *                           fname: &str) -> Result<(), std::io::Error>
+ *                                              (src/camera/mod.rs:270-317)
+ *
+ * called only from Scene::render_image (src/scene/mod.rs:332-347) right after
+ * BVHWrapper::new_wrapper(self.elements.clone()) (src/scene/mod.rs:333).
+ * Everything under that call -- cast_ray / ray_color / Hittables::hit /
+ * Materials::scatter / Textures::value / the sky lookup -- runs on the GPU
+ * behind the entry points below.  Scene building, asset decoding and the PPM
+ * text output stay on the host side of the boundary.
+ *
+ * Rust-callable by construction: #[repr(C)] PODs, caller-owned memory, int32
+ * status codes, no unwinding, no global state besides the opaque handle.  The
+ * binding a Crucible maintainer would add is shown in INTEGRATION.md.
+ *
+ * All scene numbers cross the boundary as f64 (the reference's scalar type,
+ * src/utils.rs:72-74).  The library computes either in f64 (CR_REAL_F64,
+ * arithmetic twin of the reference) or in f32 (CR_REAL_F32, inputs rounded to
+ * f32 once at upload).
+ */
+#ifndef CRUCIBLE_HIP_H
+#define CRUCIBLE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CR_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define CR_API __attribute__((visibility("default")))
+#else
+#define CR_API
+#endif
+
+/* ---- status codes (the reference panics or returns io::Error instead) ---- */
+enum {
+    CR_OK = 0,
+    CR_ERR_INVALID_ARG = 1,   /* reference: assert!/panic! in constructors          */
+    CR_ERR_NO_DEVICE = 2,     /* no HIP device / HIP runtime error at create         */
+    CR_ERR_HIP = 3,           /* any other HIP runtime failure (see cr_last_error)   */
+    CR_ERR_NO_SCENE = 4,      /* render before upload                                 */
+    CR_ERR_IO = 5,            /* file open/write failed (reference: io::Error)        */
+    CR_ERR_NAN = 6,           /* a pixel mean is NaN / outside [0,1]
+                                 (reference: Color::new assert, src/utils.rs:345-350) */
+    CR_ERR_UNSUPPORTED = 7
+};
+
+/* ---- scalar type the path computes in ---- */
+enum { CR_REAL_F32 = 0, CR_REAL_F64 = 1 };
+
+/* ---- primitives: Hittables::{Sphere,Triangle} (src/objects/mod.rs:109-115) ---- */
+enum { CR_PRIM_SPHERE = 0, CR_PRIM_TRIANGLE = 1 };
+enum { CR_PRIM_HIDDEN = 1 };   /* Sphere.hide / Triangle.hide (sphere.rs:18, triangle.rs:11) */
+
+/*
+ * One element of the flat scene list (Scene.elements, src/scene/mod.rs:77), in
+ * list order -- the order matters because the BVH build stable-sorts it
+ * (src/objects/bvhwrapper.rs:66-67).
+ *   sphere   : v[0..2] = centre, v[3] = radius          (sphere.rs:26)
+ *   triangle : v[0..2] = a, v[3..5] = b, v[6..8] = c    (triangle.rs:24)
+ * key_first/key_count select this primitive's keyframes in CrSceneDesc.keys
+ * (0 keys = static; the initial transform is the v[] values themselves).
+ */
+typedef struct CrPrimitive {
+    int32_t kind;
+    int32_t material;
+    int32_t flags;
+    int32_t key_first;
+    int32_t key_count;
+    int32_t _pad;
+    double v[9];
+} CrPrimitive;
+
+/* ---- materials: Materials::{Lambertian,Metal,Dielectric} (src/materials/mod.rs:16-21) ---- */
+enum { CR_MAT_LAMBERTIAN = 0, CR_MAT_METAL = 1, CR_MAT_DIELECTRIC = 2 };
+
+typedef struct CrMaterial {
+    int32_t kind;
+    int32_t texture;     /* Lambertian: index into textures (lambertian.rs:18)          */
+    double albedo[3];    /* Metal: albedo (metal.rs:12)                                  */
+    double param;        /* Lambertian: scatter_prob; Metal: fuzz; Dielectric: refraction_index */
+} CrMaterial;
+
+/* ---- textures: Textures::{SolidColor,CheckerTexture,ImageTexture} (src/textures/mod.rs:12-17) ---- */
+enum { CR_TEX_SOLID = 0, CR_TEX_CHECKER = 1, CR_TEX_IMAGE = 2 };
+
+typedef struct CrTexture {
+    int32_t kind;
+    int32_t even;        /* checker: texture index (checker_texture.rs:12)   */
+    int32_t odd;         /* checker: texture index (checker_texture.rs:13)   */
+    int32_t image;       /* image: index into images (image_texture.rs:11)   */
+    double color[3];     /* solid: albedo (solid_color.rs:7)                 */
+    double inv_scale;    /* checker: 1.0/scale, computed by the caller exactly as
+                            CheckerTexture::new_* does (checker_texture.rs:23,31) */
+} CrTexture;
+
+/* RTWImage after image.to_rgb8() (src/asset_loader/img_loader.rs:27-46):
+ * row-major, 3 bytes per texel, texel value = byte / 255.0. */
+typedef struct CrImage {
+    int32_t width;
+    int32_t height;
+    const uint8_t* rgb8;
+} CrImage;
+
+/* ---- Skybox (src/scene/mod.rs:18-25) ---- */
+enum { CR_SKY_DEFAULT = 0, CR_SKY_SPHERICAL = 1 };
+
+/*
+ * One flattened keyframe of a TransformTimeline (src/timeline/mod.rs:116-120),
+ * i.e. one Transform pushed by translate_{x,y,z} / scale_sphere
+ * (src/timeline/transform_builder.rs).  The authoring API stays on the host;
+ * only its evaluated form crosses the boundary.
+ *   channel 0,1,2 : translate x,y,z.  Active when t >= t0
+ *                   (valid_time.is_less(t) || contains(t), timeline/mod.rs:239).
+ *                   value = a (NERP) | a * s (LERP), s = clamp((t-t0)/(t1-t0),0,1)
+ *                   (timeline/mod.rs:90-96, transform_builder.rs `move |t| x * t`).
+ *                   Active values are added in array order (timeline/mod.rs:243-246).
+ *   channel 3     : sphere radius.  The LAST active key wins (timeline/mod.rs:249-255);
+ *                   value = a (NERP) | a + (b - a) * s (LERP).
+ */
+enum { CR_KEY_TX = 0, CR_KEY_TY = 1, CR_KEY_TZ = 2, CR_KEY_RADIUS = 3 };
+enum { CR_KEY_NERP = 0, CR_KEY_LERP = 1 };
+
+typedef struct CrKeyframe {
+    int32_t channel;
+    int32_t interp;
+    double t0, t1;
+    double a, b;
+} CrKeyframe;
+
+typedef struct CrSceneDesc {
+    int32_t n_prims;
+    int32_t n_materials;
+    int32_t n_textures;
+    int32_t n_images;
+    int32_t n_keys;
+    int32_t sky_kind;
+    int32_t sky_image;
+    int32_t _pad;
+    const CrPrimitive* prims;
+    const CrMaterial* materials;
+    const CrTexture* textures;
+    const CrImage* images;
+    const CrKeyframe* keys;
+} CrSceneDesc;
+
+/*
+ * Camera state read by the render path (src/camera/mod.rs:66-100).  Angles are
+ * passed in degrees as the reference's setters take them (set_vfov :213,
+ * set_defocus_angle :250); image_height is what Viewport::new derives
+ * (camera/mod.rs:37-38) and is passed explicitly so the caller's value wins.
+ * look_from / look_at keyframes (cam_translate_point, scene_animator.rs) are
+ * flattened like primitive keys; channels 0..2 only.
+ */
+typedef struct CrCameraDesc {
+    int32_t image_width;
+    int32_t image_height;
+    double vfov_degrees;
+    double defocus_angle_degrees;
+    double focus_dist;
+    double look_from[3];
+    double look_at[3];
+    double vup[3];
+    int32_t from_key_count;
+    int32_t at_key_count;
+    const CrKeyframe* from_keys;
+    const CrKeyframe* at_keys;
+} CrCameraDesc;
+
+/*
+ * Per-render parameters.  samples/max_depth/frame/frame_rate/shutter_angle are
+ * Camera fields (camera/mod.rs:83-99).  The reference draws every random number
+ * from an unseeded thread-local generator (rand::rng(), ray_casting.rs:74); this
+ * ABI replaces it with a counter-based generator keyed by
+ * (seed, pixel index, sample index, draw index) -- see DESIGN.md "RNG".
+ * sample_begin/sample_count select a sub-range of the `samples` sample indices
+ * (samples-per-pixel sharding across GPUs); the mean is still taken over
+ * `samples` when the sums of all shards are added.
+ */
+typedef struct CrRenderParams {
+    int32_t samples;
+    int32_t sample_begin;
+    int32_t sample_count;
+    int32_t max_depth;
+    uint64_t seed;
+    int32_t frame;
+    int32_t real_type;      /* CR_REAL_F32 | CR_REAL_F64 */
+    double frame_rate;
+    double shutter_angle;
+    int32_t output_sum;     /* 0: per-pixel mean over `samples` (average_samples,
+                               ray_casting.rs:154-173); 1: raw per-pixel sum of this shard */
+    int32_t _pad;
+} CrRenderParams;
+
+/*
+ * Work counters of the last render (the algorithmic-bytes model of DESIGN.md):
+ * segments = closest-hit queries, node_tests = BVH boxes tested,
+ * prim_tests = primitive intersection tests, texel_fetches = image texels read.
+ */
+typedef struct CrStats {
+    uint64_t samples;
+    uint64_t segments;
+    uint64_t node_tests;
+    uint64_t prim_tests;
+    uint64_t texel_fetches;
+    uint64_t nan_pixels;
+    double kernel_ms;       /* HIP-event time of the render kernel(s) on the handle's stream */
+    double upload_ms;
+    int32_t bvh_entries;
+    int32_t scene_in_lds;
+} CrStats;
+
+typedef struct CrHandle CrHandle;
+
+/* ---- entry points ---- */
+
+/* Library ABI version (CR_ABI_VERSION). */
+CR_API int32_t cr_abi_version(void);
+
+/* Create a renderer bound to one HIP device.  One handle = one caller thread at
+ * a time, like the reference's single-caller Camera (camera/mod.rs:354). */
+CR_API int32_t cr_create(int32_t device_id, CrHandle** out);
+CR_API void cr_destroy(CrHandle* h);
+
+/* Copies the whole description (the caller may free it on return), filters
+ * hidden primitives and builds the BVH in reference topology
+ * (BVHWrapper::new_wrapper, src/objects/bvhwrapper.rs:15-93) for both scalar types
+ * lazily.  Replaces the `world`/`skybox` arguments of Camera::render. */
+CR_API int32_t cr_upload_scene(CrHandle* h, const CrSceneDesc* scene);
+
+/* Camera::render minus the file output: renders into a DEVICE buffer of
+ * image_width*image_height*3 reals (f32 or f64 per params->real_type), row-major,
+ * RGB interleaved.  Asynchronous on the handle's stream unless `stats` is non-NULL
+ * (then it synchronises to fill the stats). */
+CR_API int32_t cr_render_device(CrHandle* h, const CrCameraDesc* cam, const CrRenderParams* params,
+                         void* d_out_rgb, CrStats* stats);
+
+/* Same, into a HOST buffer (render + device->host copy, synchronous). */
+CR_API int32_t cr_render_host(CrHandle* h, const CrCameraDesc* cam, const CrRenderParams* params,
+                       void* h_out_rgb, CrStats* stats);
+
+/* Block until the handle's stream is idle. */
+CR_API int32_t cr_synchronize(CrHandle* h);
+
+/* The hipStream_t the handle launches on (so a caller can order its own work). */
+CR_API void* cr_stream(CrHandle* h);
+
+/* PPM P3 writer reproducing Camera::render's output (camera/mod.rs:286,306-311) and
+ * `impl Display for Color` (src/utils.rs:422-437): (255*sqrt(c)) as u32.  `rgb` is
+ * image_width*image_height*3 host reals of `real_type` holding per-pixel means. */
+CR_API int32_t cr_write_ppm(const char* path, const void* rgb, int32_t real_type,
+                     int32_t image_width, int32_t image_height);
+
+/* Quantise means to the bytes Display would print (3 per pixel); no file. */
+CR_API int32_t cr_quantize_rgb8(const void* rgb, int32_t real_type, int64_t n_pixels, uint8_t* out);
+
+/* Last error text of this handle (NULL handle: last create error). */
+CR_API const char* cr_last_error(CrHandle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRUCIBLE_HIP_H */
