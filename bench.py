@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the render path on MI355X.
+
+One "step" = one complete render of BASELINE.json configs[1]: the book1 scene,
+1920x1080, 512 samples per pixel, depth 50, through the C ABI (cr_render_device).
+Inputs (scene, camera) are resident in HBM before the timed region; the output
+stays in HBM.  With N GPUs the 512 sample indices are split across ranks
+(rank r renders [r*512/N, (r+1)*512/N) of every pixel), the per-pixel f32 sums
+are reduced to rank 0 with one RCCL reduce and divided by 512 there -- a fixed
+job, so scaling is "strong".
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` uses the counted algorithmic-bytes model
+of DESIGN.md and the kernel time from HIP events on the launch stream;
+`cpu_baseline` times the f64 oracle (a port of the reference, NOT the Rust binary)
+on a bounded slice of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(st, width, height, entry_bytes=32, sphere_bytes=16):
+    """DESIGN.md / SURVEY.md 8(d): B = S*(2*48) + N*entry + P*s_prim + T*4 + W*H*12."""
+    return (st["segments"] * 96 + st["node_tests"] * entry_bytes + st["prim_tests"] * sphere_bytes +
+            st["texel_fetches"] * 4 + width * height * 12)
+
+
+def cpu_baseline(scene, seed, target_s=14.0):
+    """Time the f64 oracle on sample indices [0, k) of the same workload (all pixels)."""
+    from crucible_amd import _abi as A
+    from oracle.oracle import Oracle
+    threads = min(os.cpu_count() or 1, 16)
+    o = Oracle(A.CR_REAL_F64)
+    h = o.scene_create(scene.flatten())
+    cam = scene.scene_cam
+    try:
+        k, dt = 1, 0.0
+        for _ in range(4):   # grow the slice until it is >= ~10 s of CPU work (bounded at ~30 s)
+            t0 = time.perf_counter()
+            o.render(h, cam, seed=seed, sample_begin=0, sample_count=k, output_sum=True, n_threads=threads)
+            dt = time.perf_counter() - t0
+            if dt >= 0.8 * target_s or k >= cam.samples:
+                break
+            k = max(k + 1, min(cam.samples, int(k * target_s / max(dt, 1e-3))))
+    finally:
+        o.scene_destroy(h)
+    n = cam.image_width * cam.image_height * k
+    return {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"f64 oracle, book1 {cam.image_width}x{cam.image_height}, sample indices [0,{k}) of {cam.samples} "
+                      f"for every pixel ({n / 1e6:.2f} Msamples, {dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--real", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--spp", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from crucible_amd import _abi as A
+    from crucible_amd.demo_builder import book1_end_scene
+    from crucible_amd.distributed import reduce_to_mean, shard_range
+    from crucible_amd.renderer import Renderer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    real_type = A.CR_REAL_F32 if args.real == "f32" else A.CR_REAL_F64
+    tdtype = torch.float32 if args.real == "f32" else torch.float64
+    seed, scene_seed = 0xC0FFEE, 1
+    scene = book1_end_scene(1, scene_seed=scene_seed, image_width=args.width, samples=args.spp)
+    cam = scene.scene_cam
+    W, H, spp = cam.image_width, cam.image_height, cam.samples
+    s_begin, s_count = shard_range(rank, world, spp)
+
+    r = Renderer(local_rank)
+    r.upload_scene(scene.flatten())
+    out = torch.empty((H, W, 3), dtype=tdtype, device=dev)
+
+    def step():
+        r.render_device(cam, out.data_ptr(), seed=seed, real_type=real_type, sample_begin=s_begin, sample_count=s_count,
+                        output_sum=(world > 1))
+        ms = r.last_kernel_ms()          # waits for the launch (HIP events on the library's stream)
+        if world > 1:
+            reduce_to_mean(out, spp, dst=0)   # RCCL reduce of the RGB sums, then sum / count on rank 0
+        return ms
+
+    # one counted launch (untimed) for the algorithmic-bytes model; also warms the build path
+    st = r.render_device(cam, out.data_ptr(), seed=seed, real_type=real_type, sample_begin=s_begin, sample_count=s_count,
+                         output_sum=(world > 1), want_stats=True)
+    for _ in range(args.warmup):
+        step()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    for _ in range(args.steps):
+        kernel_ms += step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_samples = W * H * spp * args.steps
+        value = total_samples / elapsed / 1e6
+        entry_bytes = 32 if args.real == "f32" else 64
+        sphere_bytes = 16 if args.real == "f32" else 32
+        B = algorithmic_bytes(st, W, H, entry_bytes, sphere_bytes)
+        k_ms = kernel_ms / max(args.steps, 1)
+        achieved = B / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = f"book1_{W}x{H}_spp{s_count}_{args.real}"
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        try:
+            metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+        except Exception:
+            metric = "Msamples/sec (whole node), book1 1920x1080"
+        rec = {
+            "metric": metric, "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": args.real, "data": "synthetic",
+            "config": {"workload": f"book1 (RTIOW final scene, seeded) {W}x{H} @ {spp} spp, depth {cam.max_depth} "
+                                   "-- BASELINE.json configs[1]",
+                       "image": [W, H], "spp": spp, "max_depth": cam.max_depth, "scene_seed": scene_seed, "rng_seed": seed,
+                       "primitives": len(scene.elements), "bvh_entries": st["bvh_entries"],
+                       "scene_in_lds": bool(st["scene_in_lds"]),
+                       "parallelism": "1 GPU" if world == 1 else f"spp-shard x{world} + RCCL reduce of the f32 RGB sums"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "cr::pathtrace_kernel", "kernel_ms": round(k_ms, 4),
+                         "algorithmic_bytes_per_launch": int(B),
+                         "counters_per_launch": {k: st[k] for k in ("samples", "segments", "node_tests", "prim_tests",
+                                                                    "texel_fetches")}},
+            "kernel_msamples_per_s": round(W * H * s_count / (k_ms * 1e-3) / 1e6, 2) if k_ms > 0 else None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(scene, seed)
+        print(json.dumps(rec), flush=True)
+
+    r.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,6 +78,7 @@ SYMBOLS = {
                                      C.POINTER(CrStats)]),
     "cr_render_host": (C.c_int32, [C.c_void_p, C.POINTER(CrCameraDesc), C.POINTER(CrRenderParams), C.c_void_p,
                                    C.POINTER(CrStats)]),
+    "cr_last_kernel_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double)]),
     "cr_synchronize": (C.c_int32, [C.c_void_p]),
     "cr_stream": (C.c_void_p, [C.c_void_p]),
     "cr_write_ppm": (C.c_int32, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),

@@ -67,8 +67,10 @@ struct CrHandle {
     DevScene<double> s64;
     DevBuf work_counter, counters, att_stack, out_buf;
     double upload_ms = 0;
-    size_t lds_limit = 64 * 1024;
+    size_t lds_limit = 160 * 1024;
     int blocks_per_cu_override = 0;
+    int block_override = 0;
+    int last_block = 0, last_grid = 0;
 };
 
 namespace {
@@ -168,6 +170,18 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
     std::vector<Prim<real>> leaf_prims(n);
     for (int32_t i = 0; i < n; i++) leaf_prims[i] = src[b.order[i]];
 
+    // Device texture table: only textures a non-solid lambertian can reach (a solid top-level
+    // texture is folded into its material), re-indexed densely; children keep smaller indices.
+    std::vector<int32_t> tex_remap(h->textures.size(), -1);
+    {
+        std::vector<char> live(h->textures.size(), 0);
+        for (const CrMaterial& m : h->materials)
+            if (m.kind == CR_MAT_LAMBERTIAN && h->textures[m.texture].kind != CR_TEX_SOLID) live[m.texture] = 1;
+        for (size_t i = h->textures.size(); i-- > 0;)   // parents have larger indices than children
+            if (live[i] && h->textures[i].kind == CR_TEX_CHECKER) { live[h->textures[i].even] = 1; live[h->textures[i].odd] = 1; }
+        int32_t next = 0;
+        for (size_t i = 0; i < live.size(); i++) if (live[i]) tex_remap[i] = next++;
+    }
     std::vector<Mat<real>> mats(h->materials.size());
     for (size_t i = 0; i < mats.size(); i++) {
         const CrMaterial& m = h->materials[i];
@@ -178,16 +192,20 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
         if (m.kind == CR_MAT_LAMBERTIAN) {
             const CrTexture& t = h->textures[m.texture];
             if (t.kind == CR_TEX_SOLID) for (int k = 0; k < 3; k++) o.albedo[k] = (real)t.color[k];
-            else o.tex = m.texture;
+            else o.tex = tex_remap[m.texture];
         }
     }
-    std::vector<Tex<real>> texs(h->textures.size());
-    for (size_t i = 0; i < texs.size(); i++) {
+    std::vector<Tex<real>> texs;
+    for (size_t i = 0; i < h->textures.size(); i++) {
+        if (tex_remap[i] < 0) continue;
         const CrTexture& t = h->textures[i];
-        Tex<real>& o = texs[i];
+        Tex<real> o;
         memset(&o, 0, sizeof o);
-        o.kind = t.kind; o.even = t.even; o.odd = t.odd; o.image = t.image; o.inv_scale = (real)t.inv_scale;
+        o.kind = t.kind; o.image = t.image; o.inv_scale = (real)t.inv_scale;
+        o.even = t.kind == CR_TEX_CHECKER ? tex_remap[t.even] : -1;
+        o.odd = t.kind == CR_TEX_CHECKER ? tex_remap[t.odd] : -1;
         for (int k = 0; k < 3; k++) o.color[k] = (real)t.color[k];
+        texs.push_back(o);
     }
     // scene keys, then room for the camera's keys (copied per render)
     const size_t kMaxCamKeys = 512;
@@ -230,25 +248,34 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
     KernelArgs<real> args = args_in;
     auto kern = pathtrace_kernel<real, LDS, ANIM>;
     if (LDS) HIP_TRY(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    int per_cu = 0;
-    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, LDS ? lds_bytes : 0));
-    if (per_cu < 1) per_cu = 1;
+    // Workgroup size: the candidate that keeps the most waves resident per CU (a larger
+    // workgroup shares one LDS copy of the scene among more waves); ties go to the larger.
+    int block = 256, per_cu = 1, best_waves = 0;
+    for (int cand : {1024, 512, 256}) {
+        if (cand > MaxBlock<real>::value) continue;
+        if (h->block_override > 0 && cand != h->block_override) continue;
+        int n = 0;
+        HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, cand, LDS ? lds_bytes : 0));
+        if (n * cand / 64 > best_waves) { best_waves = n * cand / 64; block = cand; per_cu = n; }
+    }
+    if (best_waves == 0) return fail(h, CR_ERR_HIP, "kernel does not fit on a CU");
     if (h->blocks_per_cu_override > 0) per_cu = h->blocks_per_cu_override;
     uint32_t total_work = args.tiles_x * args.tiles_y * 64u;
     uint32_t grid = (uint32_t)(h->n_cus * per_cu);
-    uint32_t need_blocks = (total_work + kBlock - 1) / kBlock;
+    uint32_t need_blocks = (total_work + block - 1) / block;
     if (grid > need_blocks) grid = need_blocks;
     if (grid < 1) grid = 1;
-    args.n_threads = grid * kBlock;
+    args.n_threads = grid * (uint32_t)block;
     size_t stack_bytes = (size_t)3 * (size_t)(args.max_depth > 0 ? args.max_depth : 1) * args.n_threads * sizeof(real);
     HIP_TRY(h, h->att_stack.ensure(stack_bytes));
     args.att_stack = (real*)h->att_stack.p;
     HIP_TRY(h, hipMemsetAsync(h->work_counter.p, 0, 4, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 4 * sizeof(uint64_t), h->stream));
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), LDS ? lds_bytes : 0, h->stream, args);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), LDS ? lds_bytes : 0, h->stream, args);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    h->last_block = block; h->last_grid = (int)grid;
     if (stats) {
         HIP_TRY(h, hipEventSynchronize(h->ev1));
         float ms = 0;
@@ -390,6 +417,7 @@ int32_t cr_create(int32_t device_id, CrHandle** out) {
     if ((e = h->counters.ensure(64)) != hipSuccess) return bail("hipMalloc", e);
     if (const char* s = getenv("CRUCIBLE_LDS_LIMIT")) h->lds_limit = (size_t)atol(s);
     if (const char* s = getenv("CRUCIBLE_BLOCKS_PER_CU")) h->blocks_per_cu_override = atoi(s);
+    if (const char* s = getenv("CRUCIBLE_BLOCK")) h->block_override = atoi(s);
     *out = h;
     return CR_OK;
 }
@@ -524,6 +552,16 @@ int32_t cr_render_host(CrHandle* h, const CrCameraDesc* cam, const CrRenderParam
         if (stats) stats->nan_pixels = bad;
         if (bad) return fail(h, CR_ERR_NAN, "a pixel mean is NaN or outside [0,1] (the reference panics in Color::new)");
     }
+    return CR_OK;
+}
+
+int32_t cr_last_kernel_ms(CrHandle* h, double* out_ms) {
+    if (!h || !out_ms) return CR_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    float ms = 0;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *out_ms = ms;
     return CR_OK;
 }
 

@@ -328,13 +328,16 @@ CR_D double r_acos(double x) { return acos(x); }
 
 enum : int { ST_NEED_PIXEL = 0, ST_NEED_SAMPLE = 1, ST_TRACE = 2, ST_DONE = 3 };
 
-constexpr int kBlock = 256;
+// Largest workgroup each scalar type may be launched with.  The launch bound caps the
+// register allocation: 1024 threads = 4 waves/SIMD = 128 VGPRs (enough for f32),
+// 512 threads = 2 waves/SIMD = 256 VGPRs (the f64 kernel needs ~200).
+template <typename real> struct MaxBlock { static constexpr int value = sizeof(real) == 4 ? 1024 : 512; };
 
 // One lane = one pixel at a time, all of that pixel's samples in draw order (so the
 // per-pixel sum is the reference's sequential sum).  Lanes that finish a pixel pull the
 // next pixel index with one wave-aggregated atomic (ballot + prefix count).
 template <typename real, bool LDS_SCENE, bool ANIM>
-__global__ void __launch_bounds__(kBlock) pathtrace_kernel(const KernelArgs<real> A) {
+__global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const KernelArgs<real> A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Entry<real>* entries = A.entries;
     const Prim<real>* prims = A.prims;

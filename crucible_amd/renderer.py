@@ -25,6 +25,13 @@ def load_library():
     """dlopen the in-tree library and bind every symbol the header declares."""
     global _lib
     if _lib is None:
+        # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64; if this
+        # library pulled in /opt/rocm's copies first, torch would later load a second runtime that finds no
+        # GPU.  Importing torch first makes both share one (measured on the MI355X box, ROCm 7.2 + torch 2.10).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                     "or `make -C crucible_amd/csrc`")
@@ -87,6 +94,11 @@ class Renderer:
         self._check(self.lib.cr_render_device(self.h, C.byref(cd), C.byref(p), C.c_void_p(d_ptr),
                                               C.byref(st) if want_stats else None))
         return st.as_dict() if want_stats else None
+
+    def last_kernel_ms(self):
+        ms = C.c_double()
+        self._check(self.lib.cr_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
 
     def synchronize(self):
         self._check(self.lib.cr_synchronize(self.h))

@@ -249,6 +249,11 @@ CR_API int32_t cr_render_device(CrHandle* h, const CrCameraDesc* cam, const CrRe
 CR_API int32_t cr_render_host(CrHandle* h, const CrCameraDesc* cam, const CrRenderParams* params,
                        void* h_out_rgb, CrStats* stats);
 
+/* Wait for the last render launched on this handle and return its kernel time in
+ * milliseconds, measured with HIP events recorded on the handle's stream around the
+ * launch (no counters are copied back). */
+CR_API int32_t cr_last_kernel_ms(CrHandle* h, double* out_ms);
+
 /* Block until the handle's stream is idle. */
 CR_API int32_t cr_synchronize(CrHandle* h);
 

@@ -1,0 +1,74 @@
+"""Small scenes used by the parity tests and by tests/golden/make_golden.py."""
+import numpy as np
+
+from crucible_amd.scene import (LERP, LOCAL, NERP, WORLD, CheckerTexture, Dielectric, ImageTexture, Lambertian, Metal,
+                                RTWImage, Scene, SolidColor, Sphere, Triangle)
+
+
+def small_image(w=16, h=8, seed=3):
+    rs = np.random.RandomState(seed)
+    return RTWImage(rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8))
+
+
+def mixed_scene(width=64, samples=4, sky=True, animate=False, depth=12):
+    """Triangles + spheres, all three materials, solid / checker / nested checker / image textures,
+    spherical sky, defocus blur; optional keyframes on camera, spheres and a triangle pair."""
+    sc = Scene.new_image(16.0 / 9.0, width, 24, 180.0, 1)
+    cam = sc.scene_cam
+    cam.set_samples(samples)
+    cam.set_max_depth(depth)
+    cam.look_from((6.0, 2.5, 5.0))
+    cam.look_at((0.0, 0.6, 0.0))
+    cam.set_vfov(35.0)
+    cam.set_defocus_angle(0.8)
+    cam.set_focus_dist(7.5)
+    img = small_image()
+    nested = CheckerTexture.new_from_textures(1.5, CheckerTexture.new_from_color(0.25, (0.9, 0.1, 0.1), (0.1, 0.1, 0.9)),
+                                              ImageTexture(img))
+    sc.add_element(Sphere.new((0.0, -100.0, 0.0), 100.0, Lambertian.new_from_texture(nested, 1.0)), "ground")
+    sc.add_element(Sphere.new((0.0, 1.0, 0.0), 1.0, Dielectric.new(1.5)), "glass")
+    sc.add_element(Sphere.new((0.0, 1.0, 0.0), 0.6, Dielectric.new(1.0 / 1.5)), "bubble")
+    sc.add_element(Sphere.new((-2.2, 0.8, 0.5), 0.8, Lambertian.new_from_texture(ImageTexture(img), 0.85)), "globe")
+    sc.add_element(Sphere.new((2.2, 0.7, -0.3), 0.7, Metal.new((0.8, 0.6, 0.2), 0.3)), "brass")
+    sc.add_element(Sphere.new((1.0, 0.3, 2.0), 0.3, Metal.new((0.9, 0.9, 0.9), 0.0)), "mirror")
+    sc.add_element(Sphere.new((-1.0, 0.25, 2.2), 0.25, Lambertian.new_from_color((0.2, 0.7, 0.3), 0.6)), "matte")
+    # a quad (two triangles, one alias each) and a tetrahedron behind the spheres
+    m_quad = Metal.new((0.7, 0.7, 0.9), 0.1)
+    sc.add_element(Triangle.new((-3.0, 0.0, -2.5), (3.0, 0.0, -2.5), (3.0, 3.0, -2.5), m_quad), "quad_a")
+    sc.add_element(Triangle.new((-3.0, 0.0, -2.5), (3.0, 3.0, -2.5), (-3.0, 3.0, -2.5), m_quad), "quad_b")
+    m_tet = Lambertian.new_from_texture(CheckerTexture.new_from_color(0.4, (0.9, 0.9, 0.2), (0.2, 0.2, 0.2)), 1.0)
+    p = [(3.2, 0.0, 1.5), (4.2, 0.0, 1.2), (3.7, 0.0, 2.3), (3.7, 1.0, 1.7)]
+    for k, (a, b, c) in enumerate([(0, 1, 3), (1, 2, 3), (2, 0, 3), (0, 2, 1)]):
+        sc.add_element(Triangle.new(p[a], p[b], p[c], m_tet), f"tet{k}")
+    # an axis-aligned flat triangle alone in its BVH leaf never hits (zero-thickness box, bvh.rs:126): keep one
+    sc.add_element(Triangle.new((-4.0, 0.01, 3.0), (-3.0, 0.01, 3.0), (-3.5, 0.01, 4.0), Metal.new((1.0, 0.2, 0.2), 0.0)), "flat")
+    if sky:
+        rs = np.random.RandomState(11)
+        sc.load_spherical_skybox(RTWImage(rs.randint(60, 256, size=(16, 32, 3)).astype(np.uint8)))
+    if animate:
+        sc.cam_translate_point((7.0, 3.0, 4.0), 0.02, LERP, WORLD, "from")
+        sc.cam_translate_point((0.2, 0.5, 0.0), 0.015, LERP, WORLD, "at")
+        sc.translate_point((0.3, 0.2, 0.0), 0.01, LERP, LOCAL, "brass")
+        sc.translate_point((0.0, 0.1, 0.1), 0.012, NERP, LOCAL, "mirror")
+        sc.scale_r(0.4, 0.02, LERP, "matte")
+        sc.scale_r(0.9, 0.005, NERP, "globe")
+        sc.translate_point((0.0, 0.3, 0.0), 0.018, LERP, LOCAL, "tet0")
+    return sc
+
+
+def few_spheres(n, width=48, samples=3):
+    """n = 0, 1, 2, 3 ... primitives: the BVH edge cases (empty list, span-1 root, span-2 root, first sort)."""
+    sc = Scene.new_image(16.0 / 9.0, width, 24, 180.0, 1)
+    cam = sc.scene_cam
+    cam.set_samples(samples)
+    cam.set_max_depth(8)
+    cam.look_from((0.0, 1.0, 6.0))
+    cam.look_at((0.0, 0.5, 0.0))
+    cam.set_vfov(40.0)
+    mats = [Lambertian.new_from_color((0.8, 0.3, 0.3), 1.0), Metal.new((0.8, 0.8, 0.8), 0.1), Dielectric.new(1.5),
+            Lambertian.new_from_texture(CheckerTexture.new_from_color(0.5, (0.1, 0.1, 0.1), (0.9, 0.9, 0.9)), 1.0),
+            Lambertian.new_from_texture(SolidColor((0.3, 0.3, 0.9)), 0.5)]
+    for k in range(n):
+        x = (k - (n - 1) / 2.0) * 1.3
+        sc.add_element(Sphere.new((x, 0.5 + 0.1 * (k % 3), -0.2 * k), 0.5, mats[k % len(mats)]), f"s{k}")
+    return sc

@@ -1,0 +1,176 @@
+"""Host side of the boundary: scene builder mirror, keyframe flattening, demo scenes,
+OBJ loader, PPM writer / byte quantisation (cr_write_ppm needs no GPU)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+from crucible_amd import _abi as A
+from crucible_amd.demo_builder import SceneRng, book1_end_scene, load_teapot, procedural_sky
+from crucible_amd.scene import (LERP, LOCAL, NERP, WORLD, Camera, CheckerTexture, Lambertian, Metal, Scene, Sphere,
+                                load_obj)
+from crucible_amd.timeline import TransformTimeline
+
+
+def test_viewport_height_matches_reference_rule():   # Viewport::new, src/camera/mod.rs:37-38
+    for w, h in ((400, 225), (1920, 1080), (3840, 2160), (64, 36), (1, 1)):
+        assert Camera(16.0 / 9.0, w, 24.0, 180.0, 1).image_height == h
+
+
+def test_book1_is_deterministic_and_has_reference_shape():
+    a = book1_end_scene(1, scene_seed=1).flatten()
+    b = book1_end_scene(1, scene_seed=1).flatten()
+    assert a.desc.n_prims == b.desc.n_prims == 484   # <= 1 + 22*22 + 3 (demo_images.rs:48-84)
+    assert bytes(a.prims) == bytes(b.prims) and bytes(a.materials) == bytes(b.materials)
+    c = book1_end_scene(1, scene_seed=2).flatten()
+    assert bytes(a.prims) != bytes(c.prims)
+    p0 = a.prims[0]   # ground sphere first (demo_images.rs:35-42)
+    assert list(p0.v[0:4]) == [0.0, -1000.0, 0.0, 1000.0]
+    last = a.prims[a.desc.n_prims - 1]
+    assert list(last.v[0:4]) == [4.0, 1.0, 0.0, 1.0]
+    kinds = [a.materials[a.prims[i].material].kind for i in range(1, a.desc.n_prims - 3)]
+    frac = [kinds.count(k) / len(kinds) for k in (0, 1, 2)]
+    assert 0.7 < frac[0] < 0.9 and 0.08 < frac[1] < 0.22 and 0.01 < frac[2] < 0.1   # 80/15/5 mix
+
+
+def test_scene_rng_is_splitmix64():
+    r = SceneRng(0)   # published SplitMix64 test vector for seed 0
+    assert [r.u64() for _ in range(3)] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
+
+
+def test_alias_collision_raises():   # id_vendor.rs:51-75 / scene/mod.rs:170-174
+    sc = Scene.new_image(16 / 9, 32, 24, 180.0, 1)
+    m = Metal.new((0.5, 0.5, 0.5), 0.0)
+    sc.add_element(Sphere.new((0, 0, 0), 1.0, m), "a")
+    with pytest.raises(ValueError):
+        sc.add_element(Sphere.new((1, 0, 0), 1.0, m), "a")
+    with pytest.raises(ValueError):
+        sc.add_element(Sphere.new((1, 0, 0), 1.0, m), "cam")   # reserved
+
+
+def test_constructor_checks_mirror_reference_asserts():
+    with pytest.raises(ValueError):
+        Metal.new((0.5, 0.5, 0.5), 1.5)          # metal.rs:21
+    with pytest.raises(ValueError):
+        Sphere.new((0, 0, 0), -1.0, None)        # sphere.rs:26
+    with pytest.raises(ValueError):
+        Lambertian.new_from_color((2.0, 0, 0), 1.0)   # Color::new, utils.rs:345
+    with pytest.raises(ValueError):
+        Camera(16 / 9, 32, 24.0, 180.0, 1).set_samples(0)   # camera/mod.rs:235
+
+
+def test_hide_and_show():
+    sc = scenes.few_spheres(3)
+    sc.hide_element("s1")
+    f = sc.flatten()
+    assert [f.prims[i].flags for i in range(3)] == [0, A.CR_PRIM_HIDDEN, 0]
+    sc.show_element("s1")
+    assert sc.flatten().prims[1].flags == 0
+
+
+def test_keyframe_flattening_lerp_world():
+    """first_movie's camera walk (demo_movies.rs:33-60): World LERP keys become offsets."""
+    tl = TransformTimeline((0.0, 0.0, -12.0))
+    tl.translate_point((12.0, 0.0, 0.0), 2.5, LERP, WORLD)
+    tl.translate_point((0.0, 0.0, 12.0), 5.0, LERP, WORLD)
+    ks = tl.keyframes()
+    assert len(ks) == 6
+    x = [k for k in ks if k.channel == A.CR_KEY_TX]
+    z = [k for k in ks if k.channel == A.CR_KEY_TZ]
+    assert (x[0].t0, x[0].t1, x[0].a) == (0.0, 2.5, 12.0)       # 12 - start 0
+    assert (x[1].t0, x[1].t1, x[1].a) == (2.5, 5.0, -12.0)      # 0 - previous end 12
+    assert (z[0].a, z[1].a) == (12.0, 12.0)                     # 0-(-12), 12-0
+    assert all(k.interp == A.CR_KEY_LERP for k in ks)
+
+
+def test_keyframe_flattening_nerp_and_radius():
+    tl = TransformTimeline.new_sphere((1.0, 2.0, 3.0), 0.5)
+    tl.translate_x(4.0, 2.0, NERP, LOCAL)
+    tl.scale_sphere(2.0, 3.0, LERP)
+    tl.scale_sphere(1.0, 1.0, NERP)      # inserted earlier: list stays sorted by start
+    ks = tl.keyframes()
+    assert [(k.channel, k.interp, k.t0, k.t1, k.a, k.b) for k in ks] == [
+        (A.CR_KEY_TX, A.CR_KEY_NERP, 2.0, 2.0, 4.0, 0.0),
+        (A.CR_KEY_RADIUS, A.CR_KEY_LERP, 0.0, 3.0, 0.5, 2.0),
+        (A.CR_KEY_RADIUS, A.CR_KEY_NERP, 1.0, 1.0, 1.0, 0.0)]
+    with pytest.raises(AssertionError):
+        tl.translate_x(1.0, -1.0, NERP, LOCAL)   # keyframe before the animation start
+
+
+def test_scale_r_rejects_meshes():   # scene_animator.rs:140-150
+    sc = scenes.mixed_scene(32, 1)
+    with pytest.raises(ValueError):
+        sc.scale_r(0.5, 1.0, LERP, "quad_a")
+    with pytest.raises(KeyError):
+        sc.scale_r(0.5, 1.0, LERP, "nope")
+
+
+def test_flatten_shares_materials_and_orders_textures():
+    sc = scenes.mixed_scene(32, 1)
+    f = sc.flatten()
+    d = f.desc
+    assert d.n_prims == len(sc.elements) and d.sky_kind == A.CR_SKY_SPHERICAL
+    assert f.prims[7].material == f.prims[8].material       # the quad's two triangles share m_quad
+    for i in range(d.n_textures):                           # children before parents
+        t = f.textures[i]
+        if t.kind == A.CR_TEX_CHECKER:
+            assert 0 <= t.even < i and 0 <= t.odd < i
+    assert f.textures[0].kind == A.CR_TEX_SOLID
+    inv = [f.textures[i].inv_scale for i in range(d.n_textures) if f.textures[i].kind == A.CR_TEX_CHECKER]
+    assert 1.0 / 0.25 in inv and 1.0 / 1.5 in inv
+
+
+def test_obj_loader(tmp_path, monkeypatch):   # obj_loader.rs:66-143
+    (tmp_path / "t.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\n\nf 1 2 3\nf 1 3 4\n")
+    monkeypatch.setenv("ASSET_DIR", str(tmp_path) + "/")
+    tris = load_obj("t.obj", 2.0, (1.0, 0.0, -1.0), None)
+    assert len(tris) == 2
+    assert tris[0].a == (1.0, 0.0, -1.0) and tris[0].b == (3.0, 0.0, -1.0) and tris[1].c == (1.0, 0.0, 1.0)
+    (tmp_path / "bad.obj").write_text("v 0 0 0\nvn 0 0 1\n")
+    with pytest.raises(ValueError):
+        load_obj("bad.obj", 1.0, (0, 0, 0), None)            # "Unsupported OBJ file"
+    (tmp_path / "quad.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nf 1 2 3 4\n")
+    with pytest.raises(ValueError):
+        load_obj("quad.obj", 1.0, (0, 0, 0), None)           # triangles only
+
+
+def test_teapot_asset_loads():
+    sc = load_teapot(1, image_width=32, samples=1)
+    assert len(sc.elements) == 6320 + 1     # assets/teapot.obj: 3644 v / 6320 f, + ground
+
+
+def test_ppm_writer_and_quantiser(hiplib, tmp_path):
+    """Camera::render's file layout (camera/mod.rs:286,306-311) and Display for Color (utils.rs:422-437)."""
+    for dtype, rt in ((np.float64, A.CR_REAL_F64), (np.float32, A.CR_REAL_F32)):
+        img = np.array([[[0.529, 0.616, 0.730], [0.0, 1.0, 0.25]], [[0.5, 0.04, 0.9999], [1.0, 0.0, 1e-9]]], dtype=dtype)
+        path = str(tmp_path / f"o_{rt}.ppm")
+        assert hiplib.cr_write_ppm(path.encode(), img.ctypes.data_as(C.c_void_p), rt, 2, 2) == A.CR_OK
+        lines = open(path).read().split("\n")
+        assert lines[:3] == ["P3", "2 2", "255"]
+        assert lines[3] == "185 200 217"                     # color_display_test, utils.rs:781
+        assert lines[4] == "0 255 127"
+        expect = [[int(255.0 * np.sqrt(float(c))) for c in px] for px in img.reshape(-1, 3)]
+        assert [[int(x) for x in l.split()] for l in lines[3:7]] == expect
+        assert lines[7] == ""
+        q = np.zeros((4, 3), dtype=np.uint8)
+        assert hiplib.cr_quantize_rgb8(img.ctypes.data_as(C.c_void_p), rt, 4, q.ctypes.data_as(C.c_void_p)) == A.CR_OK
+        assert q.tolist() == expect
+    assert hiplib.cr_write_ppm(b"/nonexistent_dir/x.ppm", img.ctypes.data_as(C.c_void_p), rt, 2, 2) == A.CR_ERR_IO
+    nan = np.array([[[np.nan, -1.0, 2.0]]])
+    q = np.zeros((1, 3), dtype=np.uint8)
+    hiplib.cr_quantize_rgb8(nan.ctypes.data_as(C.c_void_p), A.CR_REAL_F64, 1, q.ctypes.data_as(C.c_void_p))
+    assert q.tolist() == [[0, 0, 255]]                       # `as u32` saturates, NaN -> 0; 255*sqrt(2) = 360 -> byte clamp
+
+
+def test_procedural_sky_is_seeded():
+    a, b = procedural_sky(64, 32, seed=7), procedural_sky(64, 32, seed=7)
+    assert np.array_equal(a.rgb8, b.rgb8) and a.rgb8.shape == (32, 64, 3)
+
+
+def test_movie_frame_count():   # scene/mod.rs:324-330
+    sc = Scene.new_movie(16 / 9, 32, 24, 180.0, 1, 10.0)
+    assert sc.compute_frame_count() == 240
+    sc.duration = 0.51
+    assert sc.compute_frame_count() == 13
