@@ -270,7 +270,7 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
     HIP_TRY(h, h->att_stack.ensure(stack_bytes));
     args.att_stack = (real*)h->att_stack.p;
     HIP_TRY(h, hipMemsetAsync(h->work_counter.p, 0, 4, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 4 * sizeof(uint64_t), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 16 * sizeof(uint64_t), h->stream));
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), LDS ? lds_bytes : 0, h->stream, args);
     HIP_TRY(h, hipGetLastError());
@@ -289,6 +289,17 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
         stats->upload_ms = h->upload_ms;
         stats->bvh_entries = args.n_entries;
         stats->scene_in_lds = LDS ? 1 : 0;
+#ifdef CR_DIAG
+        {
+            uint64_t d[16];
+            HIP_TRY(h, hipMemcpy(d, h->counters.p, sizeof d, hipMemcpyDeviceToHost));
+            const char* names[] = {"outer_iters(wave)", "inner_lane_steps", "inner_wave_steps", "leaf_lane_steps", "leaf_wave_steps", "clk_regen", "clk_trace",
+                                   "clk_shade", "clk_total", "shade_lane_sum", "trace_lane_sum", "regen_lane_sum"};
+            fprintf(stderr, "[diag] block=%d grid=%u", block, grid);
+            for (int i = 0; i < 12; i++) fprintf(stderr, " %s=%llu", names[i], (unsigned long long)d[4 + i]);
+            fprintf(stderr, "\n");
+        }
+#endif
     }
     return CR_OK;
 }
@@ -414,7 +425,7 @@ int32_t cr_create(int32_t device_id, CrHandle** out) {
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = h->work_counter.ensure(16)) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = h->counters.ensure(64)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = h->counters.ensure(16 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
     if (const char* s = getenv("CRUCIBLE_LDS_LIMIT")) h->lds_limit = (size_t)atol(s);
     if (const char* s = getenv("CRUCIBLE_BLOCKS_PER_CU")) h->blocks_per_cu_override = atoi(s);
     if (const char* s = getenv("CRUCIBLE_BLOCK")) h->block_override = atoi(s);

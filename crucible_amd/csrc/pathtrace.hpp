@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace cr {
 
@@ -255,11 +256,31 @@ CR_D bool box_hit(const real* b, V3<real> o, V3<real> inv, real tmin, real tmax)
     return !(nmax <= nmin);
 }
 
+// The same test in min/max form on (min,max) pairs, which the compiler maps onto
+// v_pk_add_f32 / v_pk_mul_f32.  Identical to box_hit whenever no slab distance is NaN, i.e.
+// whenever 1/dir is finite on every axis (then `t0 < t1 ? .. : ..` is min/max of two non-NaN
+// numbers and `a > b ? a : b` is max; signed zeros only ever feed comparisons).  Rays with an
+// infinite 1/dir component walk with box_hit instead.
+template <typename real> using Pair = real __attribute__((ext_vector_type(2)));
+CR_D float r_min(float a, float b) { return __builtin_fminf(a, b); }
+CR_D float r_max(float a, float b) { return __builtin_fmaxf(a, b); }
+CR_D double r_min(double a, double b) { return __builtin_fmin(a, b); }
+CR_D double r_max(double a, double b) { return __builtin_fmax(a, b); }
+template <typename real>
+CR_D bool box_hit_fast(const real* b, Pair<real> ox, Pair<real> oy, Pair<real> oz, Pair<real> ix, Pair<real> iy, Pair<real> iz,
+                       real tmin, real tmax) {
+    Pair<real> tx = (Pair<real>{b[0], b[1]} - ox) * ix;
+    Pair<real> ty = (Pair<real>{b[2], b[3]} - oy) * iy;
+    Pair<real> tz = (Pair<real>{b[4], b[5]} - oz) * iz;
+    real lo = r_max(r_max(r_min(tx.x, tx.y), r_min(ty.x, ty.y)), r_max(r_min(tz.x, tz.y), tmin));
+    real hi = r_min(r_min(r_max(tx.x, tx.y), r_max(ty.x, ty.y)), r_min(r_max(tz.x, tz.y), tmax));
+    return !(hi <= lo);
+}
+
 // Sphere::hit root search (sphere.rs:72-95): returns t or a negative number for a miss.
 template <typename real>
-CR_D bool sphere_t(real cx, real cy, real cz, real radius, V3<real> o, V3<real> d, real tmin, real tmax, real& t_out) {
+CR_D bool sphere_t(real cx, real cy, real cz, real radius, V3<real> o, V3<real> d, real a /* |d|^2 */, real tmin, real tmax, real& t_out) {
     V3<real> oc = sub(mk<real>(cx, cy, cz), o);
-    real a = len2(d);
     real h = dot(d, oc);
     real c = len2(oc) - radius * radius;
     real disc = h * h - a * c;
@@ -326,6 +347,14 @@ CR_D double r_asin(double x) { return asin(x); }
 CR_D float r_acos(float x) { return acosf(x); }
 CR_D double r_acos(double x) { return acos(x); }
 
+// Diagnostic build (-DCR_DIAG, scripts/diag only): per-wave phase clocks and lane-occupancy sums go to
+// counters[4..15]; the product build compiles none of it.
+#ifdef CR_DIAG
+#define CR_DIAG_ONLY(...) __VA_ARGS__
+#else
+#define CR_DIAG_ONLY(...)
+#endif
+
 enum : int { ST_NEED_PIXEL = 0, ST_NEED_SAMPLE = 1, ST_TRACE = 2, ST_DONE = 3 };
 
 // Largest workgroup each scalar type may be launched with.  The launch bound caps the
@@ -384,7 +413,10 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
     uint32_t c_seg = 0, c_prim = 0, c_tex = 0;
     unsigned long long c_node = 0;
 
+    CR_DIAG_ONLY(unsigned long long d_iter = 0, d_inner = 0, d_inner_lanes = 0, d_leaf = 0, d_leaf_lanes = 0, d_t_regen = 0, d_t_trace = 0,
+                 d_t_shade = 0, d_shade_lanes = 0, d_regen_lanes = 0, d_trace_lanes = 0; unsigned long long d_t0 = __builtin_readcyclecounter(); const unsigned long long d_begin = d_t0;)
     for (;;) {
+        CR_DIAG_ONLY(d_iter++; d_t0 = __builtin_readcyclecounter();)
         // ---------------- regeneration: pixels
         uint64_t need = __ballot(state == ST_NEED_PIXEL);
         if (need) {
@@ -442,8 +474,10 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
             state = ST_TRACE;
         }
 
+        CR_DIAG_ONLY({ unsigned long long t = __builtin_readcyclecounter(); d_t_regen += t - d_t0; d_t0 = t; })
         // ---------------- closest hit (Hittables::hit on the BVH root, interval (0.001, inf))
         bool tracing = (state == ST_TRACE);
+        CR_DIAG_ONLY(d_regen_lanes += __popcll(__ballot(depth_left == A.max_depth && tracing)); d_trace_lanes += __popcll(__ballot(tracing));)
         V3<real> col = mk<real>(0, 0, 0);   // colour returned by the innermost ray_color call
         bool finished = false;
         if (tracing && depth_left == 0) { finished = true; tracing = false; }   // ray_color: depth == 0 -> black
@@ -453,15 +487,32 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
             c_seg++;
             const real tmin = real(0.001);
             V3<real> inv = mk<real>(real(1) / rd.x, real(1) / rd.y, real(1) / rd.z);
-            int32_t idx = 0;
+            // 1/dir infinite on some axis (zero or denormal component): slab distances can be NaN,
+            // where only the compare/select form reproduces Aabb::hit
+            const bool exact_box = (r_abs(inv.x) == r_inf(real(0))) || (r_abs(inv.y) == r_inf(real(0))) || (r_abs(inv.z) == r_inf(real(0)));
+            const real dd = len2(rd);   // Sphere::hit's `a`, the same for every sphere of this segment
             const int32_t n_entries = A.n_entries;
-            while (idx < n_entries) {
-                const Entry<real> e = entries[idx];
-                c_node++;
-                bool hit = box_hit(e.b, ro, inv, tmin, best_t);
-                int32_t next = hit ? idx + 1 : e.skip;
-                if (hit && e.leaf >= 0) {
-                    int32_t first = e.leaf >> 1, count = (e.leaf & 1) + 1;
+            // while-while: every lane walks its own wrappers in the reference's order (idx+1 on a box
+            // hit, skip link on a miss); a lane that reaches a leaf wrapper parks until the other lanes
+            // have found theirs (or run out), then the leaves are intersected together.
+            auto walk = [&](auto exact_tag) {
+                constexpr bool EXACT = decltype(exact_tag)::value;
+                const Pair<real> ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
+                const Pair<real> ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+                int32_t idx = 0;
+                for (;;) {
+                    int32_t leaf = -1;
+                    while (idx < n_entries) {
+                        const Entry<real> e = entries[idx];
+                        c_node++;
+                        CR_DIAG_ONLY(d_inner++; d_inner_lanes += 65536u / (unsigned)__popcll(__ballot(true));)
+                        bool hit = EXACT ? box_hit(e.b, ro, inv, tmin, best_t) : box_hit_fast(e.b, ox, oy, oz, ix, iy, iz, tmin, best_t);
+                        idx = hit ? idx + 1 : e.skip;
+                        if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
+                    }
+                    if (leaf < 0) break;
+                    CR_DIAG_ONLY(d_leaf++; d_leaf_lanes += 65536u / (unsigned)__popcll(__ballot(true));)
+                    int32_t first = leaf >> 1, count = (leaf & 1) + 1;
                     for (int32_t k = 0; k < count; k++) {
                         const Prim<real>& p = prims[first + k];
                         c_prim++;
@@ -470,7 +521,7 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
                         real g0 = p.g[0], g1 = p.g[1], g2 = p.g[2], g3 = p.g[3];
                         if (p.kind() == 0) {
                             if (ANIM && p.key_count) timeline_eval(A.keys + p.key_first, p.key_count, rtime, g0, g1, g2, g3);
-                            h = sphere_t(g0, g1, g2, g3, ro, rd, tmin, best_t, t);
+                            h = sphere_t(g0, g1, g2, g3, ro, rd, dd, tmin, best_t, t);
                         } else {
                             V3<real> a = mk<real>(g0, g1, g2), b = mk<real>(g3, p.g[4], p.g[5]), c = mk<real>(p.g[6], p.g[7], p.g[8]);
                             if (ANIM && p.key_count) {
@@ -484,10 +535,12 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
                         if (h) { best_t = t; best = first + k; }
                     }
                 }
-                idx = next;
-            }
+            };
+            if (!exact_box) walk(std::false_type{});
+            else walk(std::true_type{});
         }
 
+        CR_DIAG_ONLY({ unsigned long long t = __builtin_readcyclecounter(); d_t_trace += t - d_t0; d_t0 = t; d_shade_lanes += __popcll(__ballot(tracing)); })
         // ---------------- shade
         if (tracing) {
             if (best >= 0) {
@@ -622,6 +675,7 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
                 state = ST_NEED_PIXEL;
             } else state = ST_NEED_SAMPLE;
         }
+        CR_DIAG_ONLY({ unsigned long long t = __builtin_readcyclecounter(); d_t_shade += t - d_t0; d_t0 = t; })
     }
 
     // flush work counters: one atomic per counter per wave
@@ -631,11 +685,21 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
         return s;
     };
     unsigned long long s0 = wave_sum(c_seg), s1 = wave_sum(c_node), s2 = wave_sum(c_prim), s3 = wave_sum(c_tex);
+    CR_DIAG_ONLY(
+        unsigned long long w_inner = wave_sum(d_inner), w_inner_w = wave_sum(d_inner_lanes), w_leaf = wave_sum(d_leaf), w_leaf_w = wave_sum(d_leaf_lanes);
+        if (lane == 0) {
+            unsigned long long* c = (unsigned long long*)A.counters;
+            atomicAdd(&c[4], d_iter); atomicAdd(&c[5], w_inner); atomicAdd(&c[6], w_inner_w >> 16); atomicAdd(&c[7], w_leaf);
+            atomicAdd(&c[8], w_leaf_w >> 16); atomicAdd(&c[9], d_t_regen); atomicAdd(&c[10], d_t_trace); atomicAdd(&c[11], d_t_shade);
+            atomicAdd(&c[12], __builtin_readcyclecounter() - d_begin); atomicAdd(&c[13], d_shade_lanes); atomicAdd(&c[14], d_trace_lanes);
+            atomicAdd(&c[15], d_regen_lanes);
+        })
     if (lane == 0) {
         atomicAdd((unsigned long long*)&A.counters[0], s0);
         atomicAdd((unsigned long long*)&A.counters[1], s1);
         atomicAdd((unsigned long long*)&A.counters[2], s2);
         atomicAdd((unsigned long long*)&A.counters[3], s3);
+
     }
 }
 #endif   // __HIPCC__

@@ -11,7 +11,7 @@ import numpy as np
 from . import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrucible_hip.so")
+LIB_PATH = os.environ.get("CRUCIBLE_HIP_LIB") or os.path.join(_HERE, "libcrucible_hip.so")   # override: diagnostic builds only
 _lib = None
 
 
