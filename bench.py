@@ -29,9 +29,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
 
 
-def algorithmic_bytes(st, width, height, entry_bytes=32, sphere_bytes=16):
+def algorithmic_bytes(st, width, height, entry_bytes=32, prim_bytes=16):
     """DESIGN.md / SURVEY.md 8(d): B = S*(2*48) + N*entry + P*s_prim + T*4 + W*H*12."""
-    return (st["segments"] * 96 + st["node_tests"] * entry_bytes + st["prim_tests"] * sphere_bytes +
+    return (st["segments"] * 96 + st["node_tests"] * entry_bytes + st["prim_tests"] * prim_bytes +
             st["texel_fetches"] * 4 + width * height * 12)
 
 
@@ -56,7 +56,7 @@ def cpu_baseline(scene, seed, target_s=14.0):
         o.scene_destroy(h)
     n = cam.image_width * cam.image_height * k
     return {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": f"f64 oracle, book1 {cam.image_width}x{cam.image_height}, sample indices [0,{k}) of {cam.samples} "
+            "sample": f"f64 oracle, same scene {cam.image_width}x{cam.image_height}, sample indices [0,{k}) of {cam.samples} "
                       f"for every pixel ({n / 1e6:.2f} Msamples, {dt:.1f} s)"}
 
 
@@ -69,12 +69,16 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--spp", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["book1", "teapot", "million", "movie"], default="book1",
+                    help="book1 = BASELINE configs[1] (the headline); teapot/million/movie = configs[2]/[3]/[4], extra lines")
+    ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL; gloo to rehearse)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from crucible_amd import _abi as A
-    from crucible_amd.demo_builder import book1_end_scene
+    from crucible_amd.demo_builder import (book1_end_scene, load_teapot, million_spheres, procedural_sky,
+                                           teapot_orbit_movie)
     from crucible_amd.distributed import reduce_to_mean, shard_range
     from crucible_amd.renderer import Renderer
 
@@ -84,35 +88,70 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     real_type = A.CR_REAL_F32 if args.real == "f32" else A.CR_REAL_F64
     tdtype = torch.float32 if args.real == "f32" else torch.float64
     seed, scene_seed = 0xC0FFEE, 1
-    scene = book1_end_scene(1, scene_seed=scene_seed, image_width=args.width, samples=args.spp)
+    prim_bytes = 16 if args.real == "f32" else 32
+    frame_sharded = False
+    if args.workload == "book1":
+        scene = book1_end_scene(1, scene_seed=scene_seed, image_width=args.width, samples=args.spp)
+        wl = "book1 (RTIOW final scene, seeded) {W}x{H} @ {spp} spp, depth {d} -- BASELINE.json configs[1]"
+    elif args.workload == "teapot":
+        spp_default = args.spp if args.spp != 512 else 1024
+        scene = load_teapot(1, image_width=args.width, samples=spp_default, sky=procedural_sky())
+        wl = "teapot.obj (6320 tris) + ground + procedural 2048x1024 env map {W}x{H} @ {spp} spp, depth {d} -- configs[2]"
+        prim_bytes = 36 if args.real == "f32" else 72
+    elif args.workload == "million":
+        width = args.width if args.width != 1920 else 3840
+        scene = million_spheres(1, scene_seed=scene_seed, image_width=width, samples=args.spp if args.spp != 512 else 256)
+        wl = "1,000,001 procedural spheres {W}x{H} @ {spp} spp, depth {d} -- configs[3]"
+    else:
+        scene = teapot_orbit_movie(1, image_width=args.width, samples=args.spp)
+        wl = "teapot orbit movie (240 frames at 24 fps), one frame per rank per step, {W}x{H} @ {spp} spp, depth {d} -- configs[4]"
+        prim_bytes = 36 if args.real == "f32" else 72
+        frame_sharded = True
     cam = scene.scene_cam
     W, H, spp = cam.image_width, cam.image_height, cam.samples
-    s_begin, s_count = shard_range(rank, world, spp)
+    if frame_sharded:
+        s_begin, s_count = 0, spp          # every rank renders whole frames; no collective
+    else:
+        s_begin, s_count = shard_range(rank, world, spp)
+    reduce = world > 1 and not frame_sharded
 
-    r = Renderer(local_rank)
+    r = Renderer(dev_index)
     r.upload_scene(scene.flatten())
     out = torch.empty((H, W, 3), dtype=tdtype, device=dev)
+    step_no = [0]
 
     def step():
+        if frame_sharded:
+            cam.frame = (step_no[0] * world + rank) % 240
+            step_no[0] += 1
         r.render_device(cam, out.data_ptr(), seed=seed, real_type=real_type, sample_begin=s_begin, sample_count=s_count,
-                        output_sum=(world > 1))
+                        output_sum=reduce)
         ms = r.last_kernel_ms()          # waits for the launch (HIP events on the library's stream)
-        if world > 1:
-            reduce_to_mean(out, spp, dst=0)   # RCCL reduce of the RGB sums, then sum / count on rank 0
+        if reduce:
+            if args.backend == "nccl":
+                reduce_to_mean(out, spp, dst=0)   # RCCL reduce of the RGB sums, then sum / count on rank 0
+            else:                                  # rehearsal backends reduce a host copy
+                host = out.cpu()
+                reduce_to_mean(host, spp, dst=0)
+                out.copy_(host)
         return ms
 
     # one counted launch (untimed) for the algorithmic-bytes model; also warms the build path
     st = r.render_device(cam, out.data_ptr(), seed=seed, real_type=real_type, sample_begin=s_begin, sample_count=s_count,
-                         output_sum=(world > 1), want_stats=True)
+                         output_sum=reduce, want_stats=True)
     for _ in range(args.warmup):
         step()
 
@@ -135,11 +174,10 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        total_samples = W * H * spp * args.steps
+        total_samples = W * H * spp * args.steps * (world if frame_sharded else 1)
         value = total_samples / elapsed / 1e6
         entry_bytes = 32 if args.real == "f32" else 64
-        sphere_bytes = 16 if args.real == "f32" else 32
-        B = algorithmic_bytes(st, W, H, entry_bytes, sphere_bytes)
+        B = algorithmic_bytes(st, W, H, entry_bytes, prim_bytes)
         k_ms = kernel_ms / max(args.steps, 1)
         achieved = B / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None
@@ -147,7 +185,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = f"book1_{W}x{H}_spp{s_count}_{args.real}"
+                key = f"{args.workload}_{W}x{H}_spp{s_count}_{args.real}"
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -158,13 +196,13 @@ def main():
         rec = {
             "metric": metric, "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": args.real, "data": "synthetic",
-            "config": {"workload": f"book1 (RTIOW final scene, seeded) {W}x{H} @ {spp} spp, depth {cam.max_depth} "
-                                   "-- BASELINE.json configs[1]",
+            "scaling": "weak" if frame_sharded else "strong", "vs_baseline": None, "dtype": args.real, "data": "synthetic",
+            "config": {"workload": wl.format(W=W, H=H, spp=spp, d=cam.max_depth),
                        "image": [W, H], "spp": spp, "max_depth": cam.max_depth, "scene_seed": scene_seed, "rng_seed": seed,
                        "primitives": len(scene.elements), "bvh_entries": st["bvh_entries"],
                        "scene_in_lds": bool(st["scene_in_lds"]),
-                       "parallelism": "1 GPU" if world == 1 else f"spp-shard x{world} + RCCL reduce of the f32 RGB sums"},
+                       "parallelism": "1 GPU" if world == 1 else (f"frame-shard x{world}, no collective" if frame_sharded else
+                                                                     f"spp-shard x{world} + {args.backend} reduce of the RGB sums")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "cr::pathtrace_kernel", "kernel_ms": round(k_ms, 4),
@@ -173,7 +211,7 @@ def main():
                                                                     "texel_fetches")}},
             "kernel_msamples_per_s": round(W * H * s_count / (k_ms * 1e-3) / 1e6, 2) if k_ms > 0 else None,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload != "million":
             rec["cpu_baseline"] = cpu_baseline(scene, seed)
         print(json.dumps(rec), flush=True)
 

@@ -169,27 +169,90 @@ def garden_skybox(threads=1, image_width=1920, samples=500, sky=None):
     return sc
 
 
+def _splitmix_stream(seed, n):
+    """First n outputs of the SceneRng stream as float64 uniforms (vectorised: the stream is counter-based)."""
+    k = np.arange(1, n + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed & _MASK) + k * np.uint64(_GAMMA)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (2.0 ** -53)
+
+
+class _PrebuiltScene(Scene):
+    """A Scene whose flat description was generated directly (a million Python Sphere objects buy nothing)."""
+
+    def flatten(self):
+        return self._flat
+
+
 def million_spheres(threads=1, scene_seed=1, half_extent=500, image_width=3840, samples=256):
     """BASELINE config 4 (no reference scene exists: the book1 recipe widened):
-    (2*half_extent)^2 small spheres, same 80/15/5 material mix and draw order, no exclusion zone."""
-    sc = Scene.new_image(16.0 / 9.0, image_width, 24, 180.0, threads)
+    (2*half_extent)^2 small spheres of radius 0.2 at (a + 0.9U, 0.2, b + 0.9U), a,b in [-h, h), with book1's
+    80/15/5 material mix and draw order (demo_images.rs:48-82) and no exclusion zone, on the r=1000 checker ground.
+    Generated straight into the flat C-ABI arrays; identical to building it sphere by sphere with SceneRng."""
+    from . import _abi as A
+    from .scene import FlatScene
+    sc = _PrebuiltScene.new_image(16.0 / 9.0, image_width, 24, 180.0, threads)
     cam = sc.scene_cam
     cam.set_samples(samples)
     cam.set_max_depth(50)
     cam.look_from((13.0, 6.0, 3.0))
     cam.look_at((0.0, 0.0, 0.0))
     cam.set_vfov(40.0)
-    sc.add_element(Sphere.new((0.0, -1000.0, 0.0), 1000.0, _checker_ground()), "ground")
-    rng = SceneRng(scene_seed)
-    n = 0
-    for a in range(-half_extent, half_extent):
-        for b in range(-half_extent, half_extent):
-            choose_mat = rng.random()
-            center = (a + 0.9 * rng.random(), 0.2, b + 0.9 * rng.random())
-            s = Sphere.new(center, 0.2, _small_sphere_material(rng, choose_mat))
-            s.id = 1
-            sc.elements.append(s)   # aliases skipped: a million dict entries buy nothing
-            n += 1
+    n = (2 * half_extent) ** 2
+    U = _splitmix_stream(scene_seed, 9 * n)
+    # walk the stream: 3 draws per sphere + 6 (lambertian) | 4 (metal) | 0 (glass)
+    off = np.empty(n, dtype=np.int64)
+    o = 0
+    ul = U.tolist()
+    for i in range(n):
+        off[i] = o
+        c = ul[o]
+        o += 9 if c < 0.8 else (7 if c < 0.95 else 3)
+    choose = U[off]
+    aa, bb = np.divmod(np.arange(n), 2 * half_extent)
+    cx = (aa - half_extent) + 0.9 * U[off + 1]
+    cz = (bb - half_extent) + 0.9 * U[off + 2]
+    lam, met = choose < 0.8, (choose >= 0.8) & (choose < 0.95)
+    prims = np.zeros(n + 1, dtype=np.dtype([("kind", "<i4"), ("material", "<i4"), ("flags", "<i4"), ("key_first", "<i4"),
+                                            ("key_count", "<i4"), ("_pad", "<i4"), ("v", "<f8", 9)]))
+    prims["v"][0, :4] = (0.0, -1000.0, 0.0, 1000.0)
+    prims["v"][1:, 0], prims["v"][1:, 1], prims["v"][1:, 2], prims["v"][1:, 3] = cx, 0.2, cz, 0.2
+    prims["material"] = np.arange(n + 1)
+    mats = np.zeros(n + 1, dtype=np.dtype([("kind", "<i4"), ("texture", "<i4"), ("albedo", "<f8", 3), ("param", "<f8")]))
+    texs = np.zeros(3 + int(lam.sum()), dtype=np.dtype([("kind", "<i4"), ("even", "<i4"), ("odd", "<i4"), ("image", "<i4"),
+                                                        ("color", "<f8", 3), ("inv_scale", "<f8")]))
+    # textures 0,1: the checker's solids; 2: the checker; then one solid per lambertian sphere
+    texs["even"], texs["odd"], texs["image"] = -1, -1, -1
+    texs["color"][0], texs["color"][1] = (0.2, 0.3, 0.1), (0.9, 0.9, 0.9)
+    texs["kind"][2], texs["even"][2], texs["odd"][2], texs["inv_scale"][2] = A.CR_TEX_CHECKER, 0, 1, 1.0 / 0.32
+    mats["kind"][0], mats["texture"][0], mats["param"][0] = A.CR_MAT_LAMBERTIAN, 2, 1.0
+    li = np.nonzero(lam)[0]
+    c1 = np.stack([U[off[li] + 3 + k] for k in range(3)], axis=1)
+    c2 = np.stack([U[off[li] + 6 + k] for k in range(3)], axis=1)
+    texs["color"][3:] = np.clip(c1 * c2, 0.0, 1.0)
+    mats["kind"][1 + li], mats["texture"][1 + li], mats["param"][1 + li] = A.CR_MAT_LAMBERTIAN, 3 + np.arange(len(li)), 1.0
+    mi = np.nonzero(met)[0]
+    mats["kind"][1 + mi], mats["texture"][1 + mi] = A.CR_MAT_METAL, -1
+    mats["albedo"][1 + mi] = np.stack([0.5 + (1.0 - 0.5) * U[off[mi] + 3 + k] for k in range(3)], axis=1)
+    mats["param"][1 + mi] = 0.0 + (0.5 - 0.0) * U[off[mi] + 6]
+    gi = np.nonzero(~lam & ~met)[0]
+    mats["kind"][1 + gi], mats["texture"][1 + gi], mats["param"][1 + gi] = A.CR_MAT_DIELECTRIC, -1, 1.5
+    mats["albedo"][1 + gi] = 1.0
+    flat = FlatScene.__new__(FlatScene)
+    flat._np = (prims, mats, texs)
+    flat.prims = (A.CrPrimitive * len(prims)).from_buffer(prims)
+    flat.materials = (A.CrMaterial * len(mats)).from_buffer(mats)
+    flat.textures = (A.CrTexture * len(texs)).from_buffer(texs)
+    flat.images = (A.CrImage * 1)()
+    flat.keys = (A.CrKeyframe * 1)()
+    flat._image_arrays = []
+    flat.desc = A.CrSceneDesc(len(prims), len(mats), len(texs), 0, 0, A.CR_SKY_DEFAULT, -1, 0, flat.prims, flat.materials,
+                              flat.textures, flat.images, flat.keys)
+    sc._flat = flat
+    sc.elements = range(n + 1)   # only len() is meaningful
     return sc
 
 
