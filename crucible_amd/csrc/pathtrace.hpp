@@ -347,6 +347,163 @@ CR_D double r_asin(double x) { return asin(x); }
 CR_D float r_acos(float x) { return acosf(x); }
 CR_D double r_acos(double x) { return acos(x); }
 
+// Camera::cast_ray's per-sample ray (ray_casting.rs:82-105): seeds the sample's RNG stream and draws
+// time, pixel offset and (with defocus) the lens point, in the reference's order.
+template <typename real, bool ANIM>
+CR_D void camera_ray(const KernelArgs<real>& A, uint32_t pix_i, uint32_t pix_j, int32_t sample, uint64_t& rng, V3<real>& ro, V3<real>& rd,
+                     real& rtime) {
+    const CamConst<real>& cam = A.cam;
+    uint32_t pixel = pix_j * (uint32_t)cam.W + pix_i;
+    rng = rng_key(A.seed_mixed, pixel, (uint32_t)sample);
+    real ts = A.current_time + rng_range<real>(rng, real(0), A.shutter_length);
+    real ox = rng_uniform<real>(rng) - real(0.5);   // sample_square, camera/mod.rs:368-376
+    real oy = rng_uniform<real>(rng) - real(0.5);
+    CamFrame<real> f;
+    if (ANIM && cam.animated) {
+        real fx = cam.from.x, fy = cam.from.y, fz = cam.from.z, fw = real(1);
+        real ax = cam.at.x, ay = cam.at.y, az = cam.at.z, aw = real(1);
+        timeline_eval(A.keys + cam.from_key_first, cam.from_key_count, ts, fx, fy, fz, fw);
+        timeline_eval(A.keys + cam.at_key_first, cam.at_key_count, ts, ax, ay, az, aw);
+        f = camera_frame(cam, mk<real>(fw * fx, fw * fy, fw * fz), mk<real>(aw * ax, aw * ay, aw * az));
+    } else {
+        f.from = cam.from; f.p00 = cam.p00; f.pdu = cam.pdu; f.pdv = cam.pdv; f.ddu = cam.ddu; f.ddv = cam.ddv;
+    }
+    V3<real> ps = add(add(f.p00, scale((real)pix_i + ox, f.pdu)), scale((real)pix_j + oy, f.pdv));   // get_pixel_pos :64-68
+    V3<real> orig = f.from;
+    if (cam.defocus_on) {   // defocus_disk_sample :104-110, random_in_unit_disk utils.rs:110-124
+        real px, py;
+        for (;;) {
+            px = rng_range<real>(rng, real(-1), real(1));
+            py = rng_range<real>(rng, real(-1), real(1));
+            if (px * px + py * py + real(0) * real(0) < real(1)) break;
+        }
+        orig = add(add(f.from, scale(px, f.ddu)), scale(py, f.ddv));
+    }
+    ro = orig; rd = sub(ps, orig); rtime = ts;
+}
+
+// What ray_color does after the closest-hit query (ray_casting.rs:122-151) for a path whose hit is
+// (best_t, best) -- best < 0 is a miss.  Returns true when the path is finished (col = the colour the
+// outermost ray_color call returns), false when it scattered (ro/rd replaced, depth_left decremented).
+// The path's non-unit attenuations live at att_stack[(level * stack_stride + stack_slot)] (3 planes).
+template <typename real, bool ANIM>
+CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<real>* mats, const Tex<real>* texs, V3<real>& ro, V3<real>& rd,
+                real rtime, uint64_t& rng, int32_t& depth_left, int32_t& stack_n, real best_t, int32_t best, uint32_t stack_stride,
+                uint32_t stack_slot, uint32_t& c_tex, V3<real>& col) {
+    const size_t plane = (size_t)A.max_depth * stack_stride;
+    if (best >= 0) {
+        const Prim<real>& p = prims[best];
+        V3<real> loc = add(ro, scale(best_t, rd));   // Ray::at
+        V3<real> n;
+        real tu = 0, tv = 0;
+        const Mat<real> m = mats[p.mat()];
+        bool need_uv = false;
+        int32_t leaf_tex = -1;
+        if (m.kind == 0 && m.tex >= 0) {   // only image textures read u,v
+            int ti = m.tex;
+            for (int guard = 0; guard < 32 && texs[ti].kind == 1; guard++) {   // checker_texture.rs:38-51
+                const Tex<real>& tx = texs[ti];
+                int32_t s = (int32_t)((uint32_t)as_i32(r_floor(tx.inv_scale * loc.x)) + (uint32_t)as_i32(r_floor(tx.inv_scale * loc.y)) +
+                                      (uint32_t)as_i32(r_floor(tx.inv_scale * loc.z)));
+                ti = (s % 2 == 0) ? tx.even : tx.odd;
+            }
+            need_uv = texs[ti].kind == 2;
+            leaf_tex = ti;
+        }
+        if (p.kind() == 0) {
+            real g0 = p.g[0], g1 = p.g[1], g2 = p.g[2], g3 = p.g[3];
+            if (ANIM && p.key_count) timeline_eval(A.keys + p.key_first, p.key_count, rtime, g0, g1, g2, g3);
+            n = divs(sub(loc, mk<real>(g0, g1, g2)), g3);   // sphere.rs:97
+            if (need_uv) {                                  // get_sphere_uv, sphere.rs:41-46
+                real theta = r_acos(-n.y);
+                real phi = r_atan2(-n.z, n.x) + RealTraits<real>::pi;
+                tu = phi / (real(2) * RealTraits<real>::pi);
+                tv = theta / RealTraits<real>::pi;
+            }
+        } else {
+            V3<real> a = mk<real>(p.g[0], p.g[1], p.g[2]), b = mk<real>(p.g[3], p.g[4], p.g[5]), c = mk<real>(p.g[6], p.g[7], p.g[8]);
+            if (ANIM && p.key_count) {
+                real w = real(1);
+                timeline_eval(A.keys + p.key_first, p.key_count, rtime, a.x, a.y, a.z, w); a = scale(w, a); w = real(1);
+                timeline_eval(A.keys + p.key_first, p.key_count, rtime, b.x, b.y, b.z, w); b = scale(w, b); w = real(1);
+                timeline_eval(A.keys + p.key_first, p.key_count, rtime, c.x, c.y, c.z, w); c = scale(w, c);
+            }
+            n = unit(cross(sub(b, a), sub(c, a)));          // safe_new, objects/mod.rs:76
+            tu = 0; tv = 0;                                 // triangle.rs:130-131
+        }
+        bool front = dot(rd, n) < real(0);                  // HitRecord::new
+        if (!front) n = neg(n);
+
+        V3<real> att = mk<real>(0, 0, 0), ndir = rd;
+        bool some;
+        if (m.kind == 0) {                                  // lambertian.rs:40-61
+            V3<real> dir = add(n, random_unit_vector<real>(rng));
+            real tol = real(1e-8);
+            if (r_abs(dir.x) < tol && r_abs(dir.y) < tol && r_abs(dir.z) < tol) dir = n;
+            V3<real> tc;
+            if (m.tex < 0) tc = mk<real>(m.albedo[0], m.albedo[1], m.albedo[2]);
+            else if (need_uv) tc = image_lookup(A.images, A.texels, texs[leaf_tex].image, tu, tv, c_tex);
+            else tc = mk<real>(texs[leaf_tex].color[0], texs[leaf_tex].color[1], texs[leaf_tex].color[2]);
+            att = c_div(tc, m.param);
+            ndir = dir;
+            some = rng_uniform<real>(rng) <= m.param;
+        } else if (m.kind == 1) {                           // metal.rs:29-42
+            V3<real> refl = reflect(rd, n);
+            refl = add(unit(refl), scale(m.param, random_unit_vector<real>(rng)));
+            att = mk<real>(m.albedo[0], m.albedo[1], m.albedo[2]);
+            ndir = refl;
+            some = dot(refl, n) > real(0);
+        } else {                                            // dielectric.rs:30-55
+            att = mk<real>(1, 1, 1);
+            real ri = front ? real(1) / m.param : m.param;
+            V3<real> ud = unit(rd);
+            real cos_theta = -(r_fmin(dot(ud, n), real(1)));
+            real sin_theta = r_sqrt(real(1) - cos_theta * cos_theta);
+            bool refl = ri * sin_theta > real(1);
+            if (!refl) {
+                real r0 = (real(1) - ri) / (real(1) + ri);
+                r0 = r0 * r0;
+                real x = real(1) - cos_theta;
+                real x2 = x * x;
+                real x5 = x * (x2 * x2);
+                refl = (r0 + (real(1) - r0) * x5) > rng_uniform<real>(rng);
+            }
+            ndir = refl ? reflect(ud, n) : refract(ud, n, ri);
+            some = true;
+        }
+        if (!some) { col = mk<real>(0, 0, 0); return true; }   // scatter None -> black
+        // attenuation * ray_color(scattered): the product is formed innermost-first, so remember the
+        // factor and multiply on the way back (ray_casting.rs:128).  (1,1,1) multiplies exactly and
+        // need not be stored.
+        if (m.kind != 2) {
+            size_t at = (size_t)stack_n * stack_stride + stack_slot;
+            A.att_stack[at] = att.x; A.att_stack[plane + at] = att.y; A.att_stack[2 * plane + at] = att.z;
+            stack_n++;
+        }
+        ro = loc; rd = ndir; depth_left--;
+        return false;
+    }
+    // sky (ray_casting.rs:133-151)
+    V3<real> ud = unit(rd);
+    if (A.sky_kind == 1) {
+        real theta = r_atan2(ud.x, ud.z);
+        real phi = r_asin(ud.y);
+        real u = (theta / (real(2) * RealTraits<real>::pi)) + real(0.5);
+        real v = (phi / RealTraits<real>::pi) + real(0.5);
+        col = image_lookup(A.images, A.texels, A.sky_image, u, v, c_tex);
+    } else {
+        real a = real(0.5) * (ud.y + real(1));
+        col = c_add(c_scale(real(1) - a, mk<real>(1, 1, 1)), c_scale(a, mk<real>(real(0.5), real(0.7), real(1))));
+    }
+    // unwind: a_1 * (a_2 * ( ... (a_n * sky)))
+    for (int32_t k = stack_n - 1; k >= 0; k--) {
+        size_t at = (size_t)k * stack_stride + stack_slot;
+        V3<real> a_k = mk<real>(A.att_stack[at], A.att_stack[plane + at], A.att_stack[2 * plane + at]);
+        col = c_mul(a_k, col);
+    }
+    return true;
+}
+
 // Diagnostic build (-DCR_DIAG, scripts/diag only): per-wave phase clocks and lane-occupancy sums go to
 // counters[4..15]; the product build compiles none of it.
 #ifdef CR_DIAG
@@ -443,33 +600,7 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
 
         // ---------------- regeneration: camera rays (cast_ray, ray_casting.rs:82-105)
         if (state == ST_NEED_SAMPLE) {
-            uint32_t pixel = pix_j * (uint32_t)cam.W + pix_i;
-            rng = rng_key(A.seed_mixed, pixel, (uint32_t)sample);
-            real ts = A.current_time + rng_range<real>(rng, real(0), A.shutter_length);
-            real ox = rng_uniform<real>(rng) - real(0.5);   // sample_square, camera/mod.rs:368-376
-            real oy = rng_uniform<real>(rng) - real(0.5);
-            CamFrame<real> f;
-            if (ANIM && cam.animated) {
-                real fx = cam.from.x, fy = cam.from.y, fz = cam.from.z, fw = real(1);
-                real ax = cam.at.x, ay = cam.at.y, az = cam.at.z, aw = real(1);
-                timeline_eval(A.keys + cam.from_key_first, cam.from_key_count, ts, fx, fy, fz, fw);
-                timeline_eval(A.keys + cam.at_key_first, cam.at_key_count, ts, ax, ay, az, aw);
-                f = camera_frame(cam, mk<real>(fw * fx, fw * fy, fw * fz), mk<real>(aw * ax, aw * ay, aw * az));
-            } else {
-                f.from = cam.from; f.p00 = cam.p00; f.pdu = cam.pdu; f.pdv = cam.pdv; f.ddu = cam.ddu; f.ddv = cam.ddv;
-            }
-            V3<real> ps = add(add(f.p00, scale((real)pix_i + ox, f.pdu)), scale((real)pix_j + oy, f.pdv));   // get_pixel_pos :64-68
-            V3<real> orig = f.from;
-            if (cam.defocus_on) {   // defocus_disk_sample :104-110, random_in_unit_disk utils.rs:110-124
-                real px, py;
-                for (;;) {
-                    px = rng_range<real>(rng, real(-1), real(1));
-                    py = rng_range<real>(rng, real(-1), real(1));
-                    if (px * px + py * py + real(0) * real(0) < real(1)) break;
-                }
-                orig = add(add(f.from, scale(px, f.ddu)), scale(py, f.ddv));
-            }
-            ro = orig; rd = sub(ps, orig); rtime = ts;
+            camera_ray<real, ANIM>(A, pix_i, pix_j, sample, rng, ro, rd, rtime);
             depth_left = A.max_depth; stack_n = 0;
             state = ST_TRACE;
         }
@@ -543,122 +674,8 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
         CR_DIAG_ONLY({ unsigned long long t = __builtin_readcyclecounter(); d_t_trace += t - d_t0; d_t0 = t; d_shade_lanes += __popcll(__ballot(tracing)); })
         // ---------------- shade
         if (tracing) {
-            if (best >= 0) {
-                const Prim<real>& p = prims[best];
-                V3<real> loc = add(ro, scale(best_t, rd));   // Ray::at
-                V3<real> n;
-                real tu = 0, tv = 0;
-                const Mat<real> m = mats[p.mat()];
-                bool need_uv = false;
-                int32_t leaf_tex = -1;
-                if (m.kind == 0 && m.tex >= 0) {   // only image textures read u,v
-                    int ti = m.tex;
-                    for (int guard = 0; guard < 32 && texs[ti].kind == 1; guard++) {   // checker_texture.rs:38-51
-                        const Tex<real>& tx = texs[ti];
-                        int32_t s = (int32_t)((uint32_t)as_i32(r_floor(tx.inv_scale * loc.x)) + (uint32_t)as_i32(r_floor(tx.inv_scale * loc.y)) +
-                                              (uint32_t)as_i32(r_floor(tx.inv_scale * loc.z)));
-                        ti = (s % 2 == 0) ? tx.even : tx.odd;
-                    }
-                    need_uv = texs[ti].kind == 2;
-                    leaf_tex = ti;
-                }
-                if (p.kind() == 0) {
-                    real g0 = p.g[0], g1 = p.g[1], g2 = p.g[2], g3 = p.g[3];
-                    if (ANIM && p.key_count) timeline_eval(A.keys + p.key_first, p.key_count, rtime, g0, g1, g2, g3);
-                    n = divs(sub(loc, mk<real>(g0, g1, g2)), g3);   // sphere.rs:97
-                    if (need_uv) {                                  // get_sphere_uv, sphere.rs:41-46
-                        real theta = r_acos(-n.y);
-                        real phi = r_atan2(-n.z, n.x) + RealTraits<real>::pi;
-                        tu = phi / (real(2) * RealTraits<real>::pi);
-                        tv = theta / RealTraits<real>::pi;
-                    }
-                } else {
-                    V3<real> a = mk<real>(p.g[0], p.g[1], p.g[2]), b = mk<real>(p.g[3], p.g[4], p.g[5]), c = mk<real>(p.g[6], p.g[7], p.g[8]);
-                    if (ANIM && p.key_count) {
-                        real w = real(1);
-                        timeline_eval(A.keys + p.key_first, p.key_count, rtime, a.x, a.y, a.z, w); a = scale(w, a); w = real(1);
-                        timeline_eval(A.keys + p.key_first, p.key_count, rtime, b.x, b.y, b.z, w); b = scale(w, b); w = real(1);
-                        timeline_eval(A.keys + p.key_first, p.key_count, rtime, c.x, c.y, c.z, w); c = scale(w, c);
-                    }
-                    n = unit(cross(sub(b, a), sub(c, a)));          // safe_new, objects/mod.rs:76
-                    tu = 0; tv = 0;                                 // triangle.rs:130-131
-                }
-                bool front = dot(rd, n) < real(0);                  // HitRecord::new
-                if (!front) n = neg(n);
-
-                V3<real> att = mk<real>(0, 0, 0), ndir = rd;
-                bool some;
-                if (m.kind == 0) {                                  // lambertian.rs:40-61
-                    V3<real> dir = add(n, random_unit_vector<real>(rng));
-                    real tol = real(1e-8);
-                    if (r_abs(dir.x) < tol && r_abs(dir.y) < tol && r_abs(dir.z) < tol) dir = n;
-                    V3<real> tc;
-                    if (m.tex < 0) tc = mk<real>(m.albedo[0], m.albedo[1], m.albedo[2]);
-                    else if (need_uv) tc = image_lookup(A.images, A.texels, texs[leaf_tex].image, tu, tv, c_tex);
-                    else tc = mk<real>(texs[leaf_tex].color[0], texs[leaf_tex].color[1], texs[leaf_tex].color[2]);
-                    att = c_div(tc, m.param);
-                    ndir = dir;
-                    some = rng_uniform<real>(rng) <= m.param;
-                } else if (m.kind == 1) {                           // metal.rs:29-42
-                    V3<real> refl = reflect(rd, n);
-                    refl = add(unit(refl), scale(m.param, random_unit_vector<real>(rng)));
-                    att = mk<real>(m.albedo[0], m.albedo[1], m.albedo[2]);
-                    ndir = refl;
-                    some = dot(refl, n) > real(0);
-                } else {                                            // dielectric.rs:30-55
-                    att = mk<real>(1, 1, 1);
-                    real ri = front ? real(1) / m.param : m.param;
-                    V3<real> ud = unit(rd);
-                    real cos_theta = -(r_fmin(dot(ud, n), real(1)));
-                    real sin_theta = r_sqrt(real(1) - cos_theta * cos_theta);
-                    bool refl = ri * sin_theta > real(1);
-                    if (!refl) {
-                        real r0 = (real(1) - ri) / (real(1) + ri);
-                        r0 = r0 * r0;
-                        real x = real(1) - cos_theta;
-                        real x2 = x * x;
-                        real x5 = x * (x2 * x2);
-                        refl = (r0 + (real(1) - r0) * x5) > rng_uniform<real>(rng);
-                    }
-                    ndir = refl ? reflect(ud, n) : refract(ud, n, ri);
-                    some = true;
-                }
-                if (some) {
-                    // attenuation * ray_color(scattered): the product is formed innermost-first,
-                    // so remember the factor and multiply on the way back (ray_casting.rs:128).
-                    // (1,1,1) multiplies exactly and need not be stored.
-                    if (m.kind != 2) {
-                        size_t plane = (size_t)A.max_depth * A.n_threads;
-                        size_t at = (size_t)stack_n * A.n_threads + gtid;
-                        A.att_stack[at] = att.x; A.att_stack[plane + at] = att.y; A.att_stack[2 * plane + at] = att.z;
-                        stack_n++;
-                    }
-                    ro = loc; rd = ndir; depth_left--;
-                } else {
-                    finished = true;                                // scatter None -> black
-                }
-            } else {
-                // sky (ray_casting.rs:133-151)
-                V3<real> ud = unit(rd);
-                if (A.sky_kind == 1) {
-                    real theta = r_atan2(ud.x, ud.z);
-                    real phi = r_asin(ud.y);
-                    real u = (theta / (real(2) * RealTraits<real>::pi)) + real(0.5);
-                    real v = (phi / RealTraits<real>::pi) + real(0.5);
-                    col = image_lookup(A.images, A.texels, A.sky_image, u, v, c_tex);
-                } else {
-                    real a = real(0.5) * (ud.y + real(1));
-                    col = c_add(c_scale(real(1) - a, mk<real>(1, 1, 1)), c_scale(a, mk<real>(real(0.5), real(0.7), real(1))));
-                }
-                // unwind: a_1 * (a_2 * ( ... (a_n * sky)))
-                size_t plane = (size_t)A.max_depth * A.n_threads;
-                for (int32_t k = stack_n - 1; k >= 0; k--) {
-                    size_t at = (size_t)k * A.n_threads + gtid;
-                    V3<real> a_k = mk<real>(A.att_stack[at], A.att_stack[plane + at], A.att_stack[2 * plane + at]);
-                    col = c_mul(a_k, col);
-                }
-                finished = true;
-            }
+            finished = shade<real, ANIM>(A, prims, mats, texs, ro, rd, rtime, rng, depth_left, stack_n, best_t, best,
+                                         A.n_threads, gtid, c_tex, col);
         }
 
         // ---------------- sample / pixel completion (average_samples, ray_casting.rs:154-173)
