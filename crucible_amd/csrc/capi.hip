@@ -6,6 +6,7 @@
 // Nothing here falls back to a CPU renderer: without a HIP device cr_create fails.
 #include "../../include/crucible_hip.h"
 #include "pathtrace.hpp"
+#include "wavefront.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -66,10 +67,20 @@ struct CrHandle {
     DevScene<float> s32;
     DevScene<double> s64;
     DevBuf work_counter, counters, att_stack, out_buf;
+    // wavefront pipeline state (wavefront.hpp)
+    DevBuf wf_job, wf_rng, wf_ray, wf_depth, wf_hit_t, wf_hit_prim, wf_chunk, wf_ctrl, wf_samples, wf_acc;
+    uint32_t* wf_ring_host = nullptr;   // host-mapped ring the extend kernel reports its queue length into
+    uint32_t* wf_ring_dev = nullptr;
+    hipEvent_t wf_ev[8] = {};
+    int pipeline = 0;                   // 0 = megakernel (default), 1 = wavefront (CRUCIBLE_PIPELINE=mega|wavefront)
+    uint32_t wf_slots = 1u << 21;
+    size_t wf_sample_bytes = (size_t)1600 << 20;
+    int wf_last_iterations = 0;
     double upload_ms = 0;
     size_t lds_limit = 160 * 1024;
     int blocks_per_cu_override = 0;
     int block_override = 0;
+    int walk_exit_lanes = 64;          // leave the walk phase once this many lanes are not walking (64 = wait for all)
     int last_block = 0, last_grid = 0;
 };
 
@@ -304,6 +315,138 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
     return CR_OK;
 }
 
+
+// ---------------------------------------------------------------- wavefront pipeline driver
+template <typename real, bool LDS, bool ANIM>
+int32_t wf_extend_config(CrHandle* h, size_t lds_bytes, int& block, int& grid) {
+    auto kern = wf_extend_kernel<real, LDS, ANIM>;
+    if (LDS) HIP_TRY(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int best_waves = 0, per_cu = 1;
+    block = 256;
+    for (int cand : {1024, 512, 256}) {
+        if (cand > MaxBlock<real>::value) continue;
+        if (h->block_override > 0 && cand != h->block_override) continue;
+        int n = 0;
+        HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, cand, LDS ? lds_bytes : 0));
+        if (n * cand / 64 > best_waves) { best_waves = n * cand / 64; block = cand; per_cu = n; }
+    }
+    if (best_waves == 0) return fail(h, CR_ERR_HIP, "extend kernel does not fit on a CU");
+    if (h->blocks_per_cu_override > 0) per_cu = h->blocks_per_cu_override;
+    grid = h->n_cus * per_cu;
+    return CR_OK;
+}
+
+template <typename real, bool LDS, bool ANIM>
+int32_t wf_run(CrHandle* h, WfArgs<real>& W, size_t lds_bytes, int32_t s_begin, int32_t s_count, int32_t batch_cap, CrStats* stats) {
+    int block = 256, grid = 1;
+    int32_t rc = wf_extend_config<real, LDS, ANIM>(h, lds_bytes, block, grid);
+    if (rc != CR_OK) return rc;
+    const size_t npix = (size_t)W.k.cam.W * W.k.cam.H;
+    const uint32_t logic_grid = (W.n_slots + 255) / 256;
+    const uint32_t fin_grid = (uint32_t)((npix + 255) / 256);
+    HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 16 * sizeof(uint64_t), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->wf_acc.p, 0, npix * 3 * sizeof(real), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->wf_job.p, 0xFF, (size_t)W.n_slots * 4, h->stream));
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    int iterations = 0;
+    const int LAG = 4, RING = 8;
+    for (int32_t b0 = s_begin; b0 < s_begin + s_count; b0 += batch_cap) {
+        W.batch_begin = b0;
+        W.batch_samples = std::min(batch_cap, s_begin + s_count - b0);
+        W.n_jobs = (uint32_t)W.batch_samples * W.total_work;
+        W.last_batch = (b0 + W.batch_samples >= s_begin + s_count) ? 1 : 0;
+        HIP_TRY(h, hipMemsetAsync(h->wf_ctrl.p, 0, 1024, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->wf_chunk.p, 0, ((size_t)W.n_slots / 64 + 1) * 8, h->stream));
+        for (int it = 0;; it++) {
+            W.ctrl_set = (uint32_t)(it & 1);
+            W.ring_slot = h->wf_ring_dev + (it % RING);
+            hipLaunchKernelGGL((wf_logic_kernel<real, ANIM>), dim3(logic_grid), dim3(256), 0, h->stream, W);
+            hipLaunchKernelGGL((wf_extend_kernel<real, LDS, ANIM>), dim3(grid), dim3(block), LDS ? lds_bytes : 0, h->stream, W);
+            HIP_TRY(h, hipEventRecord(h->wf_ev[it % RING], h->stream));
+            iterations++;
+            if (it >= LAG) {   // lagged check: the GPU is already LAG iterations ahead, so it never waits for the host
+                int k = it - LAG;
+                HIP_TRY(h, hipEventSynchronize(h->wf_ev[k % RING]));
+                if (h->wf_ring_host[k % RING] == 0) break;   // logic found nothing to trace and no job left: batch done
+            }
+        }
+        hipLaunchKernelGGL((wf_finalize_kernel<real>), dim3(fin_grid), dim3(256), 0, h->stream, W);
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    h->last_block = block; h->last_grid = grid; h->wf_last_iterations = iterations;
+    if (stats) {
+        HIP_TRY(h, hipEventSynchronize(h->ev1));
+        float ms = 0;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        uint64_t c[4];
+        HIP_TRY(h, hipMemcpy(c, h->counters.p, sizeof c, hipMemcpyDeviceToHost));
+        memset(stats, 0, sizeof *stats);
+        stats->kernel_ms = ms;
+        stats->segments = c[0]; stats->node_tests = c[1]; stats->prim_tests = c[2]; stats->texel_fetches = c[3];
+        stats->samples = (uint64_t)npix * (uint64_t)s_count;
+        stats->upload_ms = h->upload_ms;
+        stats->bvh_entries = W.k.n_entries;
+        stats->scene_in_lds = LDS ? 1 : 0;
+#ifdef CR_DIAG
+        {
+            uint64_t d[16];
+            HIP_TRY(h, hipMemcpy(d, h->counters.p, sizeof d, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[diag-wf] block=%d grid=%d iterations=%d rounds=%llu walk_wave_steps=%llu leaf_lane=%llu leaf_wave=%llu clk_refill=%llu clk_walk=%llu clk_leaf=%llu clk_total=%llu lane_steps=%llu\n",
+                    block, grid, iterations, (unsigned long long)d[4], (unsigned long long)d[5], (unsigned long long)d[6], (unsigned long long)d[7],
+                    (unsigned long long)d[8], (unsigned long long)d[9], (unsigned long long)d[10], (unsigned long long)d[11], (unsigned long long)d[1]);
+        }
+#endif
+    }
+    return CR_OK;
+}
+
+template <typename real>
+int32_t render_wavefront(CrHandle* h, const KernelArgs<real>& a, DevScene<real>& ds, bool anim, CrStats* stats) {
+    WfArgs<real> W;
+    memset(&W, 0, sizeof W);
+    W.k = a;
+    const size_t npix = (size_t)a.cam.W * a.cam.H;
+    const int32_t s_begin = a.sample_begin, s_count = a.sample_end - a.sample_begin;
+    W.total_work = a.tiles_x * a.tiles_y * 64u;
+    // samples per batch: bounded by the per-sample colour buffer and by 32-bit job ids
+    int64_t cap = (int64_t)(h->wf_sample_bytes / (npix * 3 * sizeof(real)));
+    cap = std::min<int64_t>(cap, (int64_t)0xF0000000u / W.total_work);
+    cap = std::max<int64_t>(1, std::min<int64_t>(cap, std::max(1, s_count)));
+    const uint64_t jobs_first = (uint64_t)cap * W.total_work;
+    W.n_slots = (uint32_t)std::min<uint64_t>(h->wf_slots, (jobs_first + 63) / 64 * 64);
+    const size_t N = W.n_slots;
+    HIP_TRY(h, h->wf_job.ensure(N * 4));
+    HIP_TRY(h, h->wf_rng.ensure(N * 8));
+    HIP_TRY(h, h->wf_ray.ensure(N * 7 * sizeof(real)));
+    HIP_TRY(h, h->wf_depth.ensure(N * 4));
+    HIP_TRY(h, h->wf_hit_t.ensure(N * sizeof(real)));
+    HIP_TRY(h, h->wf_hit_prim.ensure(N * 4));
+    HIP_TRY(h, h->wf_chunk.ensure((N / 64 + 1) * 8));
+    HIP_TRY(h, h->wf_ctrl.ensure(1024));
+    HIP_TRY(h, h->wf_samples.ensure((size_t)cap * npix * 3 * sizeof(real)));
+    HIP_TRY(h, h->wf_acc.ensure(npix * 3 * sizeof(real)));
+    HIP_TRY(h, h->att_stack.ensure((size_t)3 * (size_t)std::max(1, a.max_depth) * N * sizeof(real)));
+    if (!h->wf_ring_host) {
+        HIP_TRY(h, hipHostMalloc((void**)&h->wf_ring_host, 64, hipHostMallocMapped));
+        HIP_TRY(h, hipHostGetDevicePointer((void**)&h->wf_ring_dev, h->wf_ring_host, 0));
+        for (int i = 0; i < 8; i++) HIP_TRY(h, hipEventCreateWithFlags(&h->wf_ev[i], hipEventDisableTiming));
+    }
+    W.k.att_stack = (real*)h->att_stack.p;
+    W.k.n_threads = W.n_slots;
+    W.job = (uint32_t*)h->wf_job.p; W.rng = (uint64_t*)h->wf_rng.p; W.ray = (real*)h->wf_ray.p; W.depth = (int32_t*)h->wf_depth.p;
+    W.hit_t = (real*)h->wf_hit_t.p; W.hit_prim = (int32_t*)h->wf_hit_prim.p; W.job_chunk = (uint32_t*)h->wf_chunk.p;
+    W.ctrl = (uint32_t*)h->wf_ctrl.p; W.sample_rgb = (real*)h->wf_samples.p; W.acc = (real*)h->wf_acc.p;
+    // the extend kernel stages entries | primitives only
+    auto r16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t lds_bytes = r16((size_t)ds.n_entries * sizeof(Entry<real>)) + r16((size_t)ds.n_prims * sizeof(Prim<real>));
+    const bool lds = lds_bytes <= h->lds_limit && ds.n_entries > 0;
+    const int32_t bc = (int32_t)cap;
+    if (lds) return anim ? wf_run<real, true, true>(h, W, lds_bytes, s_begin, s_count, bc, stats)
+                         : wf_run<real, true, false>(h, W, lds_bytes, s_begin, s_count, bc, stats);
+    return anim ? wf_run<real, false, true>(h, W, 0, s_begin, s_count, bc, stats) : wf_run<real, false, false>(h, W, 0, s_begin, s_count, bc, stats);
+}
+
 template <typename real>
 int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* p, void* d_out, CrStats* stats) {
     int32_t rc = build_dev_scene<real>(h);
@@ -364,8 +507,10 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     a.work_counter = (uint32_t*)h->work_counter.p;
     a.counters = (uint64_t*)h->counters.p;
     a.out = (real*)d_out;
+    a.walk_exit_lanes = (uint32_t)h->walk_exit_lanes;
 
     const bool anim = ds.animated || c.animated;
+    if (h->pipeline == 1) return render_wavefront<real>(h, a, ds, anim, stats);
     const bool lds = ds.lds_bytes <= h->lds_limit && ds.n_entries > 0;
     if (lds) return anim ? launch<real, true, true>(h, a, ds.lds_bytes, stats) : launch<real, true, false>(h, a, ds.lds_bytes, stats);
     return anim ? launch<real, false, true>(h, a, 0, stats) : launch<real, false, false>(h, a, 0, stats);
@@ -429,6 +574,10 @@ int32_t cr_create(int32_t device_id, CrHandle** out) {
     if (const char* s = getenv("CRUCIBLE_LDS_LIMIT")) h->lds_limit = (size_t)atol(s);
     if (const char* s = getenv("CRUCIBLE_BLOCKS_PER_CU")) h->blocks_per_cu_override = atoi(s);
     if (const char* s = getenv("CRUCIBLE_BLOCK")) h->block_override = atoi(s);
+    if (const char* s = getenv("CRUCIBLE_WALK_EXIT")) h->walk_exit_lanes = std::min(64, std::max(1, atoi(s)));
+    if (const char* s = getenv("CRUCIBLE_PIPELINE")) h->pipeline = (strcmp(s, "mega") == 0) ? 0 : 1;
+    if (const char* s = getenv("CRUCIBLE_WF_SLOTS")) h->wf_slots = (uint32_t)std::max(64L, atol(s));
+    if (const char* s = getenv("CRUCIBLE_WF_SAMPLE_MB")) h->wf_sample_bytes = (size_t)std::max(1L, atol(s)) << 20;
     *out = h;
     return CR_OK;
 }
@@ -440,6 +589,9 @@ void cr_destroy(CrHandle* h) {
     h->s32.release(); h->s64.release();
     h->images.release(); h->texels.release(); h->work_counter.release(); h->counters.release();
     h->att_stack.release(); h->out_buf.release();
+    h->wf_job.release(); h->wf_rng.release(); h->wf_ray.release(); h->wf_depth.release(); h->wf_hit_t.release(); h->wf_hit_prim.release();
+    h->wf_chunk.release(); h->wf_ctrl.release(); h->wf_samples.release(); h->wf_acc.release();
+    if (h->wf_ring_host) { (void)hipHostFree(h->wf_ring_host); for (int i = 0; i < 8; i++) if (h->wf_ev[i]) (void)hipEventDestroy(h->wf_ev[i]); }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);

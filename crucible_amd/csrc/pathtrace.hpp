@@ -187,6 +187,7 @@ template <typename real> struct KernelArgs {
     real* att_stack;          // 3 planes of max_depth * n_threads
     uint32_t n_threads;
     real* out;
+    uint32_t walk_exit_lanes;   // megakernel: leave the walk once this many lanes are done walking (speed only)
 };
 
 // ------------------------------------------------------------------ timeline (timeline/mod.rs:233-263)
@@ -512,7 +513,9 @@ CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<re
 #define CR_DIAG_ONLY(...)
 #endif
 
-enum : int { ST_NEED_PIXEL = 0, ST_NEED_SAMPLE = 1, ST_TRACE = 2, ST_DONE = 3 };
+// TRACE: has a ray whose walk has not begun; WALK: walking (state kept across rounds of the outer loop);
+// SHADE: closest hit known.
+enum : int { ST_NEED_PIXEL = 0, ST_NEED_SAMPLE = 1, ST_TRACE = 2, ST_DONE = 3, ST_WALK = 4, ST_SHADE = 5 };
 
 // Largest workgroup each scalar type may be launched with.  The launch bound caps the
 // register allocation: 1024 threads = 4 waves/SIMD = 128 VGPRs (enough for f32),
@@ -569,6 +572,13 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
     int32_t depth_left = 0, stack_n = 0;
     uint32_t c_seg = 0, c_prim = 0, c_tex = 0;
     unsigned long long c_node = 0;
+    // walk state, kept across rounds: a lane whose walk is cut short resumes where it stopped
+    V3<real> inv = mk<real>(0, 0, 0);
+    real best_t = 0, dd = 0;
+    int32_t best = -1, idx = 0;
+    bool exact_box = false;
+    const real tmin = real(0.001);
+    const int32_t n_entries = A.n_entries;
 
     CR_DIAG_ONLY(unsigned long long d_iter = 0, d_inner = 0, d_inner_lanes = 0, d_leaf = 0, d_leaf_lanes = 0, d_t_regen = 0, d_t_trace = 0,
                  d_t_shade = 0, d_shade_lanes = 0, d_regen_lanes = 0, d_trace_lanes = 0; unsigned long long d_t0 = __builtin_readcyclecounter(); const unsigned long long d_begin = d_t0;)
@@ -607,41 +617,54 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
 
         CR_DIAG_ONLY({ unsigned long long t = __builtin_readcyclecounter(); d_t_regen += t - d_t0; d_t0 = t; })
         // ---------------- closest hit (Hittables::hit on the BVH root, interval (0.001, inf))
-        bool tracing = (state == ST_TRACE);
-        CR_DIAG_ONLY(d_regen_lanes += __popcll(__ballot(depth_left == A.max_depth && tracing)); d_trace_lanes += __popcll(__ballot(tracing));)
+        CR_DIAG_ONLY(d_regen_lanes += __popcll(__ballot(depth_left == A.max_depth && state == ST_TRACE)); d_trace_lanes += __popcll(__ballot(state == ST_TRACE));)
         V3<real> col = mk<real>(0, 0, 0);   // colour returned by the innermost ray_color call
         bool finished = false;
-        if (tracing && depth_left == 0) { finished = true; tracing = false; }   // ray_color: depth == 0 -> black
-        real best_t = r_inf(real(0));
-        int32_t best = -1;
-        if (tracing) {
-            c_seg++;
-            const real tmin = real(0.001);
-            V3<real> inv = mk<real>(real(1) / rd.x, real(1) / rd.y, real(1) / rd.z);
-            // 1/dir infinite on some axis (zero or denormal component): slab distances can be NaN,
-            // where only the compare/select form reproduces Aabb::hit
-            const bool exact_box = (r_abs(inv.x) == r_inf(real(0))) || (r_abs(inv.y) == r_inf(real(0))) || (r_abs(inv.z) == r_inf(real(0)));
-            const real dd = len2(rd);   // Sphere::hit's `a`, the same for every sphere of this segment
-            const int32_t n_entries = A.n_entries;
-            // while-while: every lane walks its own wrappers in the reference's order (idx+1 on a box
-            // hit, skip link on a miss); a lane that reaches a leaf wrapper parks until the other lanes
-            // have found theirs (or run out), then the leaves are intersected together.
-            auto walk = [&](auto exact_tag) {
-                constexpr bool EXACT = decltype(exact_tag)::value;
-                const Pair<real> ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
-                const Pair<real> ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
-                int32_t idx = 0;
-                for (;;) {
-                    int32_t leaf = -1;
-                    while (idx < n_entries) {
-                        const Entry<real> e = entries[idx];
-                        c_node++;
-                        CR_DIAG_ONLY(d_inner++; d_inner_lanes += 65536u / (unsigned)__popcll(__ballot(true));)
-                        bool hit = EXACT ? box_hit(e.b, ro, inv, tmin, best_t) : box_hit_fast(e.b, ox, oy, oz, ix, iy, iz, tmin, best_t);
-                        idx = hit ? idx + 1 : e.skip;
-                        if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
+        if (state == ST_TRACE) {
+            if (depth_left == 0) finished = true;   // ray_color: depth == 0 -> black
+            else {
+                c_seg++;
+                inv = mk<real>(real(1) / rd.x, real(1) / rd.y, real(1) / rd.z);
+                // 1/dir infinite on some axis (zero or denormal component): slab distances can be NaN,
+                // where only the compare/select form reproduces Aabb::hit
+                exact_box = (r_abs(inv.x) == r_inf(real(0))) || (r_abs(inv.y) == r_inf(real(0))) || (r_abs(inv.z) == r_inf(real(0)));
+                dd = len2(rd);   // Sphere::hit's `a`, the same for every sphere of this segment
+                idx = 0; best_t = r_inf(real(0)); best = -1;
+                state = n_entries > 0 ? ST_WALK : ST_SHADE;
+            }
+        }
+        // while-while: every lane walks its own wrappers in the reference's order (idx+1 on a box hit,
+        // skip link on a miss); a lane that reaches a leaf wrapper parks until the other walking lanes
+        // have found theirs (or run out), then the leaves are intersected together.  After each such
+        // round the wave may leave the walk if enough lanes are done: the stragglers keep idx / best and
+        // resume on the next round of the outer loop, so each lane still performs BVHWrapper::hit's
+        // exact sequence; only the interleaving with other lanes' shading changes.
+        if (__ballot(state == ST_WALK)) {
+            const Pair<real> ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
+            const Pair<real> ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+            for (;;) {
+                int32_t leaf = -1;
+                if (state == ST_WALK) {
+                    if (!exact_box) {
+                        while (idx < n_entries) {
+                            const Entry<real> e = entries[idx];
+                            c_node++;
+                            CR_DIAG_ONLY(d_inner++; d_inner_lanes += 65536u / (unsigned)__popcll(__ballot(true));)
+                            bool hit = box_hit_fast(e.b, ox, oy, oz, ix, iy, iz, tmin, best_t);
+                            idx = hit ? idx + 1 : e.skip;
+                            if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
+                        }
+                    } else {
+                        while (idx < n_entries) {
+                            const Entry<real> e = entries[idx];
+                            c_node++;
+                            bool hit = box_hit(e.b, ro, inv, tmin, best_t);
+                            idx = hit ? idx + 1 : e.skip;
+                            if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
+                        }
                     }
-                    if (leaf < 0) break;
+                }
+                if (leaf >= 0) {
                     CR_DIAG_ONLY(d_leaf++; d_leaf_lanes += 65536u / (unsigned)__popcll(__ballot(true));)
                     int32_t first = leaf >> 1, count = (leaf & 1) + 1;
                     for (int32_t k = 0; k < count; k++) {
@@ -666,16 +689,19 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
                         if (h) { best_t = t; best = first + k; }
                     }
                 }
-            };
-            if (!exact_box) walk(std::false_type{});
-            else walk(std::true_type{});
+                if (state == ST_WALK && idx >= n_entries) state = ST_SHADE;
+                const uint64_t walking = __ballot(state == ST_WALK);
+                if (!walking || 64u - (uint32_t)__popcll(walking) >= A.walk_exit_lanes) break;
+            }
         }
+        const bool tracing = (state == ST_SHADE);
 
         CR_DIAG_ONLY({ unsigned long long t = __builtin_readcyclecounter(); d_t_trace += t - d_t0; d_t0 = t; d_shade_lanes += __popcll(__ballot(tracing)); })
         // ---------------- shade
         if (tracing) {
             finished = shade<real, ANIM>(A, prims, mats, texs, ro, rd, rtime, rng, depth_left, stack_n, best_t, best,
                                          A.n_threads, gtid, c_tex, col);
+            state = ST_TRACE;   // scattered: a fresh ray to walk (overwritten below when the path finished)
         }
 
         // ---------------- sample / pixel completion (average_samples, ray_casting.rs:154-173)

@@ -204,6 +204,47 @@ def test_teapot_with_environment_map(renderer, oracles, rt, tag):
     assert (img == ref).all(axis=2).mean() > 0.98
 
 
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+@pytest.mark.parametrize("env", [{"CRUCIBLE_PIPELINE": "wavefront"}, {"CRUCIBLE_PIPELINE": "wavefront", "CRUCIBLE_WF_SLOTS": "4096", "CRUCIBLE_WF_SAMPLE_MB": "1"},
+                                 {"CRUCIBLE_WALK_EXIT": "24"}, {"CRUCIBLE_BLOCK": "256"}],
+                         ids=["wavefront", "wavefront-small-batches", "walk-exit-24", "block-256"])
+def test_alternative_schedules_are_bit_identical(oracles, monkeypatch, rt, tag, env):
+    """The wavefront pipeline (logic / extend / finalize kernels over SoA path state, also with tiny slot counts
+    and many sample batches), an early walk exit and another workgroup size only change WHEN a path's operations
+    run, never which: images and counters stay bit-equal to the oracle."""
+    from crucible_amd.renderer import Renderer
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    r = Renderer(0)   # the handle reads the knobs at creation
+    try:
+        for sc in (book1_end_scene(1, scene_seed=1, image_width=100, samples=5), scenes.mixed_scene(56, 4, sky=False, animate=True),
+                   scenes.few_spheres(0), scenes.few_spheres(3)):
+            if sc.scene_cam.image_width == 56:
+                from crucible_amd.scene import Lambertian
+                for e in sc.elements:   # no image textures: keep the comparison libm-free
+                    if e.id in (sc._aliases["globe"][0], sc._aliases["ground"][0]):
+                        e.mat = Lambertian.new_from_color((0.4, 0.5, 0.6), 0.9)
+            img, st = gpu_render(r, sc, rt)
+            ref, rst = oracles[rt].render_image(sc, seed=SEED)
+            assert_exact(img, st, ref, rst)
+        sc = book1_end_scene(1, scene_seed=1, image_width=64, samples=7)
+        sc.scene_cam.set_max_depth(0)
+        img, _ = gpu_render(r, sc, rt)
+        assert not img.any()
+        sc.scene_cam.set_max_depth(50)
+        r.upload_scene(sc.flatten())
+        a, _ = r.render(sc.scene_cam, seed=SEED, real_type=rt, sample_begin=2, sample_count=4, output_sum=True)
+        o = oracles[rt]
+        h = o.scene_create(sc.flatten())
+        try:
+            b, _ = o.render(h, sc.scene_cam, seed=SEED, sample_begin=2, sample_count=4, output_sum=True)
+        finally:
+            o.scene_destroy(h)
+        assert np.array_equal(a.reshape(-1, 3), b)
+    finally:
+        r.close()
+
+
 def test_device_output_and_async_path(renderer):
     import torch
     sc = book1_end_scene(1, scene_seed=1, image_width=72, samples=3)
