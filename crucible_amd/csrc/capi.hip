@@ -78,9 +78,11 @@ struct CrHandle {
     int wf_last_iterations = 0;
     double upload_ms = 0;
     size_t lds_limit = 160 * 1024;
+    size_t lds_top_bytes = 64 * 1024;   // LDS spent on the top of a tree that does not fit whole (CRUCIBLE_LDS_TOP_KB; 0 = none)
     int blocks_per_cu_override = 0;
     int block_override = 0;
-    int walk_exit_lanes = 64;          // leave the walk phase once this many lanes are not walking (64 = wait for all)
+    int walk_round_steps = 12;         // 0 = a round lasts until every walking lane found a leaf or ran out (measured: 12)
+    int walk_exit_lanes = 56;          // leave the walk phase once this many lanes are not walking (64 = wait for all; measured: 56)
     int last_block = 0, last_grid = 0;
 };
 
@@ -141,6 +143,35 @@ template <typename real> struct Builder {
         build(mid, end);
         entries[idx].skip = (int32_t)entries.size();
     }
+
+    // DFS pre-order -> level order with explicit links.  In pre-order the left child of inner entry i is
+    // i + 1 and `skip` already names the next wrapper after the subtree; storing the tree level by level
+    // (stable in DFS order within a level) puts the top of the tree first, which is what a partial LDS
+    // copy wants.  The walk order is unchanged: it follows the links, not the storage order.
+    void relayout_bfs() {
+        const int32_t n = (int32_t)entries.size();
+        if (n == 0) return;
+        std::vector<int32_t> level(n, 0), order_idx(n), new_of(n + 1);
+        std::vector<int32_t> stack_end;   // ends (skip) of the enclosing inner wrappers
+        for (int32_t i = 0; i < n; i++) {
+            while (!stack_end.empty() && stack_end.back() <= i) stack_end.pop_back();
+            level[i] = (int32_t)stack_end.size();
+            if (entries[i].leaf < 0) stack_end.push_back(entries[i].skip);
+        }
+        for (int32_t i = 0; i < n; i++) order_idx[i] = i;
+        std::stable_sort(order_idx.begin(), order_idx.end(), [&](int32_t a, int32_t b) { return level[a] < level[b]; });
+        for (int32_t k = 0; k < n; k++) new_of[order_idx[k]] = k;
+        new_of[n] = n;
+        std::vector<Entry<real>> out(n);
+        for (int32_t k = 0; k < n; k++) {
+            const int32_t i = order_idx[k];
+            Entry<real> e = entries[i];
+            e.skip = new_of[e.skip];
+            if (e.leaf < 0) e.leaf = -new_of[i + 1];   // left child
+            out[k] = e;
+        }
+        entries.swap(out);
+    }
 };
 
 template <typename real> int32_t build_dev_scene(CrHandle* h) {
@@ -177,7 +208,7 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
             }
         }
     }
-    if (n > 0) b.build(0, n);
+    if (n > 0) { b.build(0, n); b.relayout_bfs(); }
     std::vector<Prim<real>> leaf_prims(n);
     for (int32_t i = 0; i < n; i++) leaf_prims[i] = src[b.order[i]];
 
@@ -254,10 +285,11 @@ template <typename real> void key_to_real(const CrKeyframe& k, Key<real>& o) {
     o.t0 = (real)k.t0; o.t1 = (real)k.t1; o.a = (real)k.a; o.b = (real)k.b; o.channel = k.channel; o.interp = k.interp;
 }
 
-template <typename real, bool LDS, bool ANIM>
+template <typename real, int RES, bool ANIM>
 int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, CrStats* stats) {
+    constexpr bool LDS = RES != RES_GLOBAL;
     KernelArgs<real> args = args_in;
-    auto kern = pathtrace_kernel<real, LDS, ANIM>;
+    auto kern = pathtrace_kernel<real, RES, ANIM>;
     if (LDS) HIP_TRY(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     // Workgroup size: the candidate that keeps the most waves resident per CU (a larger
     // workgroup shares one LDS copy of the scene among more waves); ties go to the larger.
@@ -299,7 +331,7 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
         stats->samples = (uint64_t)args.cam.W * (uint64_t)args.cam.H * (uint64_t)(args.sample_end - args.sample_begin);
         stats->upload_ms = h->upload_ms;
         stats->bvh_entries = args.n_entries;
-        stats->scene_in_lds = LDS ? 1 : 0;
+        stats->scene_in_lds = RES;
 #ifdef CR_DIAG
         {
             uint64_t d[16];
@@ -317,9 +349,10 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
 
 
 // ---------------------------------------------------------------- wavefront pipeline driver
-template <typename real, bool LDS, bool ANIM>
+template <typename real, int RES, bool ANIM>
 int32_t wf_extend_config(CrHandle* h, size_t lds_bytes, int& block, int& grid) {
-    auto kern = wf_extend_kernel<real, LDS, ANIM>;
+    constexpr bool LDS = RES != RES_GLOBAL;
+    auto kern = wf_extend_kernel<real, RES, ANIM>;
     if (LDS) HIP_TRY(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     int best_waves = 0, per_cu = 1;
     block = 256;
@@ -336,10 +369,11 @@ int32_t wf_extend_config(CrHandle* h, size_t lds_bytes, int& block, int& grid) {
     return CR_OK;
 }
 
-template <typename real, bool LDS, bool ANIM>
+template <typename real, int RES, bool ANIM>
 int32_t wf_run(CrHandle* h, WfArgs<real>& W, size_t lds_bytes, int32_t s_begin, int32_t s_count, int32_t batch_cap, CrStats* stats) {
+    constexpr bool LDS = RES != RES_GLOBAL;
     int block = 256, grid = 1;
-    int32_t rc = wf_extend_config<real, LDS, ANIM>(h, lds_bytes, block, grid);
+    int32_t rc = wf_extend_config<real, RES, ANIM>(h, lds_bytes, block, grid);
     if (rc != CR_OK) return rc;
     const size_t npix = (size_t)W.k.cam.W * W.k.cam.H;
     const uint32_t logic_grid = (W.n_slots + 255) / 256;
@@ -361,7 +395,7 @@ int32_t wf_run(CrHandle* h, WfArgs<real>& W, size_t lds_bytes, int32_t s_begin, 
             W.ctrl_set = (uint32_t)(it & 1);
             W.ring_slot = h->wf_ring_dev + (it % RING);
             hipLaunchKernelGGL((wf_logic_kernel<real, ANIM>), dim3(logic_grid), dim3(256), 0, h->stream, W);
-            hipLaunchKernelGGL((wf_extend_kernel<real, LDS, ANIM>), dim3(grid), dim3(block), LDS ? lds_bytes : 0, h->stream, W);
+            hipLaunchKernelGGL((wf_extend_kernel<real, RES, ANIM>), dim3(grid), dim3(block), LDS ? lds_bytes : 0, h->stream, W);
             HIP_TRY(h, hipEventRecord(h->wf_ev[it % RING], h->stream));
             iterations++;
             if (it >= LAG) {   // lagged check: the GPU is already LAG iterations ahead, so it never waits for the host
@@ -387,7 +421,7 @@ int32_t wf_run(CrHandle* h, WfArgs<real>& W, size_t lds_bytes, int32_t s_begin, 
         stats->samples = (uint64_t)npix * (uint64_t)s_count;
         stats->upload_ms = h->upload_ms;
         stats->bvh_entries = W.k.n_entries;
-        stats->scene_in_lds = LDS ? 1 : 0;
+        stats->scene_in_lds = RES;
 #ifdef CR_DIAG
         {
             uint64_t d[16];
@@ -437,14 +471,22 @@ int32_t render_wavefront(CrHandle* h, const KernelArgs<real>& a, DevScene<real>&
     W.job = (uint32_t*)h->wf_job.p; W.rng = (uint64_t*)h->wf_rng.p; W.ray = (real*)h->wf_ray.p; W.depth = (int32_t*)h->wf_depth.p;
     W.hit_t = (real*)h->wf_hit_t.p; W.hit_prim = (int32_t*)h->wf_hit_prim.p; W.job_chunk = (uint32_t*)h->wf_chunk.p;
     W.ctrl = (uint32_t*)h->wf_ctrl.p; W.sample_rgb = (real*)h->wf_samples.p; W.acc = (real*)h->wf_acc.p;
-    // the extend kernel stages entries | primitives only
+    // the extend kernel stages entries | primitives when both fit, else the top levels of the tree
     auto r16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    const size_t lds_bytes = r16((size_t)ds.n_entries * sizeof(Entry<real>)) + r16((size_t)ds.n_prims * sizeof(Prim<real>));
-    const bool lds = lds_bytes <= h->lds_limit && ds.n_entries > 0;
+    const size_t full = r16((size_t)ds.n_entries * sizeof(Entry<real>)) + r16((size_t)ds.n_prims * sizeof(Prim<real>));
     const int32_t bc = (int32_t)cap;
-    if (lds) return anim ? wf_run<real, true, true>(h, W, lds_bytes, s_begin, s_count, bc, stats)
-                         : wf_run<real, true, false>(h, W, lds_bytes, s_begin, s_count, bc, stats);
-    return anim ? wf_run<real, false, true>(h, W, 0, s_begin, s_count, bc, stats) : wf_run<real, false, false>(h, W, 0, s_begin, s_count, bc, stats);
+    if (ds.n_entries > 0 && full <= h->lds_limit) {
+        W.k.lds_entries = ds.n_entries;
+        return anim ? wf_run<real, RES_LDS, true>(h, W, full, s_begin, s_count, bc, stats) : wf_run<real, RES_LDS, false>(h, W, full, s_begin, s_count, bc, stats);
+    }
+    const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, h->lds_top_bytes / sizeof(Entry<real>));
+    if (top > 0) {
+        W.k.lds_entries = top;
+        const size_t bytes = (size_t)top * sizeof(Entry<real>);
+        return anim ? wf_run<real, RES_TOP, true>(h, W, bytes, s_begin, s_count, bc, stats) : wf_run<real, RES_TOP, false>(h, W, bytes, s_begin, s_count, bc, stats);
+    }
+    W.k.lds_entries = 0;
+    return anim ? wf_run<real, RES_GLOBAL, true>(h, W, 0, s_begin, s_count, bc, stats) : wf_run<real, RES_GLOBAL, false>(h, W, 0, s_begin, s_count, bc, stats);
 }
 
 template <typename real>
@@ -508,12 +550,22 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     a.counters = (uint64_t*)h->counters.p;
     a.out = (real*)d_out;
     a.walk_exit_lanes = (uint32_t)h->walk_exit_lanes;
+    a.walk_round_steps = (uint32_t)h->walk_round_steps;
 
     const bool anim = ds.animated || c.animated;
     if (h->pipeline == 1) return render_wavefront<real>(h, a, ds, anim, stats);
-    const bool lds = ds.lds_bytes <= h->lds_limit && ds.n_entries > 0;
-    if (lds) return anim ? launch<real, true, true>(h, a, ds.lds_bytes, stats) : launch<real, true, false>(h, a, ds.lds_bytes, stats);
-    return anim ? launch<real, false, true>(h, a, 0, stats) : launch<real, false, false>(h, a, 0, stats);
+    if (ds.n_entries > 0 && ds.lds_bytes <= h->lds_limit) {
+        a.lds_entries = ds.n_entries;
+        return anim ? launch<real, RES_LDS, true>(h, a, ds.lds_bytes, stats) : launch<real, RES_LDS, false>(h, a, ds.lds_bytes, stats);
+    }
+    const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, h->lds_top_bytes / sizeof(Entry<real>));
+    if (top > 0) {   // large scene: the top levels of the tree in LDS, everything else through L2
+        a.lds_entries = top;
+        const size_t bytes = (size_t)top * sizeof(Entry<real>);
+        return anim ? launch<real, RES_TOP, true>(h, a, bytes, stats) : launch<real, RES_TOP, false>(h, a, bytes, stats);
+    }
+    a.lds_entries = 0;
+    return anim ? launch<real, RES_GLOBAL, true>(h, a, 0, stats) : launch<real, RES_GLOBAL, false>(h, a, 0, stats);
 }
 
 int32_t validate_render(CrHandle* h, const CrCameraDesc* cam, const CrRenderParams* p) {
@@ -572,8 +624,10 @@ int32_t cr_create(int32_t device_id, CrHandle** out) {
     if ((e = h->work_counter.ensure(16)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = h->counters.ensure(16 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
     if (const char* s = getenv("CRUCIBLE_LDS_LIMIT")) h->lds_limit = (size_t)atol(s);
+    if (const char* s = getenv("CRUCIBLE_LDS_TOP_KB")) h->lds_top_bytes = (size_t)std::max(0L, atol(s)) * 1024;
     if (const char* s = getenv("CRUCIBLE_BLOCKS_PER_CU")) h->blocks_per_cu_override = atoi(s);
     if (const char* s = getenv("CRUCIBLE_BLOCK")) h->block_override = atoi(s);
+    if (const char* s = getenv("CRUCIBLE_WALK_ROUND")) h->walk_round_steps = std::max(0, atoi(s));
     if (const char* s = getenv("CRUCIBLE_WALK_EXIT")) h->walk_exit_lanes = std::min(64, std::max(1, atoi(s)));
     if (const char* s = getenv("CRUCIBLE_PIPELINE")) h->pipeline = (strcmp(s, "mega") == 0) ? 0 : 1;
     if (const char* s = getenv("CRUCIBLE_WF_SLOTS")) h->wf_slots = (uint32_t)std::max(64L, atol(s));

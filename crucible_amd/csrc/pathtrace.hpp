@@ -120,11 +120,14 @@ template <typename real> CR_HD V3<real> random_unit_vector(uint64_t& s) {   // u
 }
 
 // ------------------------------------------------------------------ device scene layout
-// Threaded BVH: the reference's wrapper tree (bvhwrapper.rs:46-78) in DFS pre-order.
-// A walk that goes to idx+1 on a box hit and to `skip` on a miss visits exactly the
+// Threaded BVH: the reference's wrapper tree (bvhwrapper.rs:46-78) with explicit links.
+// A walk that goes to the left child on a box hit and to `skip` (the next wrapper in DFS
+// pre-order after this subtree; n_entries = none) on a miss or after a leaf visits exactly the
 // wrappers BVHWrapper::hit visits, in the same order (left subtree, then right).
-// leaf < 0: inner wrapper.  leaf >= 0: span-1 or span-2 wrapper whose children are
-// primitives: first = leaf >> 1, count = (leaf & 1) + 1, in leaf order.
+// leaf < 0: inner wrapper, left child = -leaf.  leaf >= 0: span-1 or span-2 wrapper whose
+// children are primitives: first = leaf >> 1, count = (leaf & 1) + 1, in leaf order.
+// Entries are stored level by level (BFS), so the first K entries are the top of the tree:
+// scenes too large for LDS keep those K in LDS and read the rest through L2.
 template <typename real> struct alignas(16) Entry {
     real b[6];      // xmin, xmax, ymin, ymax, zmin, zmax
     int32_t skip;
@@ -175,6 +178,7 @@ template <typename real> struct KernelArgs {
     const uint32_t* texels;
     const Key<real>* keys;
     int32_t n_entries, n_prims, n_mats, n_texs;
+    int32_t lds_entries;      // entries staged in LDS (all of them, or the top levels of a large tree)
     int32_t sky_kind, sky_image;
     CamConst<real> cam;
     int32_t sample_begin, sample_end, samples_total, max_depth;
@@ -188,6 +192,7 @@ template <typename real> struct KernelArgs {
     uint32_t n_threads;
     real* out;
     uint32_t walk_exit_lanes;   // megakernel: leave the walk once this many lanes are done walking (speed only)
+    uint32_t walk_round_steps;  // wrappers a lane may step through before the wave intersects the parked leaves (speed only)
 };
 
 // ------------------------------------------------------------------ timeline (timeline/mod.rs:233-263)
@@ -505,6 +510,17 @@ CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<re
     return true;
 }
 
+// Where the scene is read from: RES_GLOBAL everything through L2; RES_LDS entries | primitives |
+// materials | textures staged in LDS; RES_TOP only the first lds_entries wrappers (top levels) in LDS.
+enum : int { RES_GLOBAL = 0, RES_LDS = 1, RES_TOP = 2 };
+
+template <typename real, int RES>
+CR_D Entry<real> fetch_entry(const Entry<real>* lds, const Entry<real>* glob, int32_t lds_entries, int32_t idx) {
+    if (RES == RES_LDS) return lds[idx];
+    if (RES == RES_TOP) return idx < lds_entries ? lds[idx] : glob[idx];
+    return glob[idx];
+}
+
 // Diagnostic build (-DCR_DIAG, scripts/diag only): per-wave phase clocks and lane-occupancy sums go to
 // counters[4..15]; the product build compiles none of it.
 #ifdef CR_DIAG
@@ -525,35 +541,33 @@ template <typename real> struct MaxBlock { static constexpr int value = sizeof(r
 // One lane = one pixel at a time, all of that pixel's samples in draw order (so the
 // per-pixel sum is the reference's sequential sum).  Lanes that finish a pixel pull the
 // next pixel index with one wave-aggregated atomic (ballot + prefix count).
-template <typename real, bool LDS_SCENE, bool ANIM>
+template <typename real, int RES, bool ANIM>
 __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const KernelArgs<real> A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Entry<real>* entries = A.entries;
+    const Entry<real>* lds_entries = nullptr;
     const Prim<real>* prims = A.prims;
     const Mat<real>* mats = A.mats;
     const Tex<real>* texs = A.texs;
-    if (LDS_SCENE) {
-        // stage the whole scene: entries | prims | mats | texs, each 16-B aligned
-        size_t o0 = 0;
-        size_t o1 = o0 + (((size_t)A.n_entries * sizeof(Entry<real>) + 15) & ~(size_t)15);
-        size_t o2 = o1 + (((size_t)A.n_prims * sizeof(Prim<real>) + 15) & ~(size_t)15);
-        size_t o3 = o2 + (((size_t)A.n_mats * sizeof(Mat<real>) + 15) & ~(size_t)15);
-        size_t o4 = o3 + (((size_t)A.n_texs * sizeof(Tex<real>) + 15) & ~(size_t)15);
+    if (RES != RES_GLOBAL) {
         auto copy = [&](const void* src, size_t off, size_t bytes) {
             const uint32_t* s = (const uint32_t*)src;
             uint32_t* d = (uint32_t*)(smem + off);
             for (size_t i = threadIdx.x; i < bytes / 4; i += blockDim.x) d[i] = s[i];
         };
-        copy(A.entries, o0, (size_t)A.n_entries * sizeof(Entry<real>));
-        copy(A.prims, o1, (size_t)A.n_prims * sizeof(Prim<real>));
-        copy(A.mats, o2, (size_t)A.n_mats * sizeof(Mat<real>));
-        copy(A.texs, o3, (size_t)A.n_texs * sizeof(Tex<real>));
-        (void)o4;
+        copy(A.entries, 0, (size_t)A.lds_entries * sizeof(Entry<real>));
+        lds_entries = (const Entry<real>*)smem;
+        if (RES == RES_LDS) {   // the whole scene: entries | prims | mats | texs, each 16-B aligned
+            size_t o1 = (((size_t)A.n_entries * sizeof(Entry<real>) + 15) & ~(size_t)15);
+            size_t o2 = o1 + (((size_t)A.n_prims * sizeof(Prim<real>) + 15) & ~(size_t)15);
+            size_t o3 = o2 + (((size_t)A.n_mats * sizeof(Mat<real>) + 15) & ~(size_t)15);
+            copy(A.prims, o1, (size_t)A.n_prims * sizeof(Prim<real>));
+            copy(A.mats, o2, (size_t)A.n_mats * sizeof(Mat<real>));
+            copy(A.texs, o3, (size_t)A.n_texs * sizeof(Tex<real>));
+            prims = (const Prim<real>*)(smem + o1);
+            mats = (const Mat<real>*)(smem + o2);
+            texs = (const Tex<real>*)(smem + o3);
+        }
         __syncthreads();
-        entries = (const Entry<real>*)(smem + o0);
-        prims = (const Prim<real>*)(smem + o1);
-        mats = (const Mat<real>*)(smem + o2);
-        texs = (const Tex<real>*)(smem + o3);
     }
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -646,20 +660,22 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
                 int32_t leaf = -1;
                 if (state == ST_WALK) {
                     if (!exact_box) {
+                        uint32_t budget = A.walk_round_steps;   // bounds how long lanes parked on a leaf wait for the others
                         while (idx < n_entries) {
-                            const Entry<real> e = entries[idx];
+                            const Entry<real> e = fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, idx);
                             c_node++;
                             CR_DIAG_ONLY(d_inner++; d_inner_lanes += 65536u / (unsigned)__popcll(__ballot(true));)
                             bool hit = box_hit_fast(e.b, ox, oy, oz, ix, iy, iz, tmin, best_t);
-                            idx = hit ? idx + 1 : e.skip;
+                            idx = (hit && e.leaf < 0) ? -e.leaf : e.skip;
                             if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
+                            if (--budget == 0) break;
                         }
                     } else {
                         while (idx < n_entries) {
-                            const Entry<real> e = entries[idx];
+                            const Entry<real> e = fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, idx);
                             c_node++;
                             bool hit = box_hit(e.b, ro, inv, tmin, best_t);
-                            idx = hit ? idx + 1 : e.skip;
+                            idx = (hit && e.leaf < 0) ? -e.leaf : e.skip;
                             if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
                         }
                     }

@@ -149,29 +149,31 @@ __global__ void __launch_bounds__(256) wf_logic_kernel(const WfArgs<real> W) {
     }
 }
 
-template <typename real, bool LDS_SCENE, bool ANIM>
+template <typename real, int RES, bool ANIM>
 __global__ void __launch_bounds__(MaxBlock<real>::value) wf_extend_kernel(const WfArgs<real> W) {
     const KernelArgs<real>& A = W.k;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Entry<real>* entries = A.entries;
+    const Entry<real>* lds_entries = nullptr;
     const Prim<real>* prims = A.prims;
     uint32_t* my_set = &W.ctrl[WF_SET * W.ctrl_set];
     uint32_t q_count = 0;
     for (int i = 0; i < 32; i++) q_count += my_set[i];
     if (blockIdx.x == 0 && threadIdx.x == 0) *W.ring_slot = q_count;
     if (q_count == 0) return;
-    if (LDS_SCENE) {   // entries | prims only: shading does not run here
-        size_t o1 = (((size_t)A.n_entries * sizeof(Entry<real>) + 15) & ~(size_t)15);
+    if (RES != RES_GLOBAL) {   // entries (all or the top levels) and, when they fit, the primitives: shading does not run here
         auto copy = [&](const void* src, size_t off, size_t bytes) {
             const uint32_t* s = (const uint32_t*)src;
             uint32_t* d = (uint32_t*)(smem + off);
             for (size_t i = threadIdx.x; i < bytes / 4; i += blockDim.x) d[i] = s[i];
         };
-        copy(A.entries, 0, (size_t)A.n_entries * sizeof(Entry<real>));
-        copy(A.prims, o1, (size_t)A.n_prims * sizeof(Prim<real>));
+        copy(A.entries, 0, (size_t)A.lds_entries * sizeof(Entry<real>));
+        lds_entries = (const Entry<real>*)smem;
+        if (RES == RES_LDS) {
+            size_t o1 = (((size_t)A.n_entries * sizeof(Entry<real>) + 15) & ~(size_t)15);
+            copy(A.prims, o1, (size_t)A.n_prims * sizeof(Prim<real>));
+            prims = (const Prim<real>*)(smem + o1);
+        }
         __syncthreads();
-        entries = (const Entry<real>*)smem;
-        prims = (const Prim<real>*)(smem + o1);
     }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t N = W.n_slots;
@@ -233,19 +235,19 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) wf_extend_kernel(const 
         if (has_ray) {
             if (!exact_box) {
                 while (idx < n_entries) {
-                    const Entry<real> e = entries[idx];
+                    const Entry<real> e = fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, idx);
                     c_node++;
                     CR_DIAG_ONLY(d_w += 65536u / (unsigned)__popcll(__ballot(true));)
                     bool hit = box_hit_fast(e.b, ox, oy, oz, ix, iy, iz, tmin, best_t);
-                    idx = hit ? idx + 1 : e.skip;
+                    idx = (hit && e.leaf < 0) ? -e.leaf : e.skip;
                     if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
                 }
             } else {
                 while (idx < n_entries) {
-                    const Entry<real> e = entries[idx];
+                    const Entry<real> e = fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, idx);
                     c_node++;
                     bool hit = box_hit(e.b, ro, inv, tmin, best_t);
-                    idx = hit ? idx + 1 : e.skip;
+                    idx = (hit && e.leaf < 0) ? -e.leaf : e.skip;
                     if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
                 }
             }
