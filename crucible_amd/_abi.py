@@ -82,6 +82,8 @@ SYMBOLS = {
     "cr_synchronize": (C.c_int32, [C.c_void_p]),
     "cr_stream": (C.c_void_p, [C.c_void_p]),
     "cr_write_ppm": (C.c_int32, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "cr_write_ppm_binary": (C.c_int32, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "cr_write_png": (C.c_int32, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "cr_quantize_rgb8": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
     "cr_last_error": (C.c_char_p, [C.c_void_p]),
 }

@@ -14,8 +14,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
+#include <thread>
 #include <vector>
+#include <zlib.h>
 
 using namespace cr;
 
@@ -117,7 +120,32 @@ template <typename real> struct Builder {
     std::vector<int32_t> order;
     std::vector<Entry<real>> entries;
 
-    void build(int32_t start, int32_t end) {
+    // Number of wrappers of a range of `span` primitives: a pure function of the span (median split),
+    // so every subtree's position in the pre-order array is known before it is built and subtrees can
+    // be built by independent threads.
+    static int32_t tree_size(int32_t span) {
+        if (span <= 2) return span > 0 ? 1 : 0;
+        return 1 + tree_size(span / 2) + tree_size(span - span / 2);   // depth log2(n), two distinct spans per level
+    }
+
+    void build_root(int32_t n) {
+        sizes.clear();
+        entries.assign((size_t)size_of(n), Entry<real>());
+        build(0, n, 0, 0);
+    }
+
+  private:
+    std::map<int32_t, int32_t> sizes;
+    int32_t size_of(int32_t span) {
+        if (span <= 2) return span > 0 ? 1 : 0;
+        auto it = sizes.find(span);
+        if (it != sizes.end()) return it->second;
+        int32_t v = 1 + size_of(span / 2) + size_of(span - span / 2);
+        sizes[span] = v;
+        return v;
+    }
+
+    void build(int32_t start, int32_t end, int32_t idx, int depth) {
         real lo[3], hi[3];
         for (int a = 0; a < 3; a++) { lo[a] = r_inf(real(0)); hi[a] = -r_inf(real(0)); }
         for (int32_t i = start; i < end; i++) {
@@ -130,20 +158,31 @@ template <typename real> struct Builder {
         real sx = hi[0] - lo[0], sy = hi[1] - lo[1], sz = hi[2] - lo[2];
         int axis = (sx > sy) ? ((sx > sz) ? 0 : 2) : ((sy > sz) ? 1 : 2);
         int32_t span = end - start;
-        int32_t idx = (int32_t)entries.size();
         Entry<real> e;
         e.b[0] = lo[0]; e.b[1] = hi[0]; e.b[2] = lo[1]; e.b[3] = hi[1]; e.b[4] = lo[2]; e.b[5] = hi[2];
         e.skip = idx + 1; e.leaf = -1;
-        entries.push_back(e);
-        if (span <= 2) { entries[idx].leaf = (start << 1) | (span - 1); return; }
+        if (span <= 2) { e.leaf = (start << 1) | (span - 1); entries[idx] = e; return; }
         const std::vector<real>& key = bmin[axis];
         std::stable_sort(order.begin() + start, order.begin() + end, [&](int32_t a, int32_t b) { return key[a] < key[b]; });
         int32_t mid = start + span / 2;
-        build(start, mid);
-        build(mid, end);
-        entries[idx].skip = (int32_t)entries.size();
+        const int32_t left_idx = idx + 1, right_idx = idx + 1 + sizes_at(span / 2);
+        e.skip = idx + sizes_at(span);
+        entries[idx] = e;
+        if (depth < 4 && span >= (1 << 15)) {   // the two halves touch disjoint ranges of `order` and `entries`
+            std::thread t([&] { build(start, mid, left_idx, depth + 1); });
+            build(mid, end, right_idx, depth + 1);
+            t.join();
+        } else {
+            build(start, mid, left_idx, depth + 1);
+            build(mid, end, right_idx, depth + 1);
+        }
+    }
+    int32_t sizes_at(int32_t span) const {   // read-only after build_root filled the table (thread-safe)
+        if (span <= 2) return span > 0 ? 1 : 0;
+        return sizes.at(span);
     }
 
+  public:
     // DFS pre-order -> level order with explicit links.  In pre-order the left child of inner entry i is
     // i + 1 and `skip` already names the next wrapper after the subtree; storing the tree level by level
     // (stable in DFS order within a level) puts the top of the tree first, which is what a partial LDS
@@ -208,7 +247,7 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
             }
         }
     }
-    if (n > 0) { b.build(0, n); b.relayout_bfs(); }
+    if (n > 0) { b.build_root(n); b.relayout_bfs(); }
     std::vector<Prim<real>> leaf_prims(n);
     for (int32_t i = 0; i < n; i++) leaf_prims[i] = src[b.order[i]];
 
@@ -813,6 +852,54 @@ int32_t cr_write_ppm(const char* path, const void* rgb, int32_t real_type, int32
         for (int k = 0; k < 3; k++) c[k] = real_type == CR_REAL_F64 ? ((const double*)rgb)[3 * i + k] : (double)((const float*)rgb)[3 * i + k];
         ok = fprintf(f, "%u %u %u\n", display_byte(c[0]), display_byte(c[1]), display_byte(c[2])) > 0;
     }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? CR_OK : CR_ERR_IO;
+}
+
+int32_t cr_write_ppm_binary(const char* path, const void* rgb, int32_t real_type, int32_t w, int32_t hgt) {
+    if (!path || !rgb || w < 1 || hgt < 1 || (real_type != CR_REAL_F32 && real_type != CR_REAL_F64)) return CR_ERR_INVALID_ARG;
+    std::vector<uint8_t> bytes((size_t)w * hgt * 3);
+    if (cr_quantize_rgb8(rgb, real_type, (int64_t)w * hgt, bytes.data()) != CR_OK) return CR_ERR_INVALID_ARG;
+    FILE* f = fopen(path, "wb");
+    if (!f) return CR_ERR_IO;
+    bool ok = fprintf(f, "P6\n%d %d\n255\n", w, hgt) > 0 && fwrite(bytes.data(), 1, bytes.size(), f) == bytes.size();
+    ok = (fclose(f) == 0) && ok;
+    return ok ? CR_OK : CR_ERR_IO;
+}
+
+int32_t cr_write_png(const char* path, const void* rgb, int32_t real_type, int32_t w, int32_t hgt) {
+    if (!path || !rgb || w < 1 || hgt < 1 || (real_type != CR_REAL_F32 && real_type != CR_REAL_F64)) return CR_ERR_INVALID_ARG;
+    const size_t row = (size_t)w * 3;
+    std::vector<uint8_t> raw((row + 1) * hgt);   // filter byte 0 (None) + RGB8 per scanline
+    {
+        std::vector<uint8_t> bytes(row * hgt);
+        if (cr_quantize_rgb8(rgb, real_type, (int64_t)w * hgt, bytes.data()) != CR_OK) return CR_ERR_INVALID_ARG;
+        for (int32_t y = 0; y < hgt; y++) { raw[(row + 1) * y] = 0; memcpy(&raw[(row + 1) * y + 1], &bytes[row * y], row); }
+    }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 1) != Z_OK) return CR_ERR_IO;   // level 1: output speed matters, not size
+    FILE* f = fopen(path, "wb");
+    if (!f) return CR_ERR_IO;
+    auto be32 = [](uint8_t* p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; };
+    bool ok = true;
+    auto chunk = [&](const char* type, const uint8_t* data, uint32_t len) {
+        uint8_t hdr[8];
+        be32(hdr, len); memcpy(hdr + 4, type, 4);
+        uint32_t crc = (uint32_t)crc32(0L, (const Bytef*)type, 4);
+        if (len) crc = (uint32_t)crc32(crc, data, len);
+        uint8_t tail[4];
+        be32(tail, crc);
+        ok = ok && fwrite(hdr, 1, 8, f) == 8 && (len == 0 || fwrite(data, 1, len, f) == len) && fwrite(tail, 1, 4, f) == 4;
+    };
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    ok = fwrite(sig, 1, 8, f) == 8;
+    uint8_t ihdr[13];
+    be32(ihdr, (uint32_t)w); be32(ihdr + 4, (uint32_t)hgt);
+    ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;   // 8-bit, colour type 2 (RGB), no interlace
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", z.data(), (uint32_t)zlen);
+    chunk("IEND", nullptr, 0);
     ok = (fclose(f) == 0) && ok;
     return ok ? CR_OK : CR_ERR_IO;
 }

@@ -113,6 +113,15 @@ class Renderer:
         if rc != A.CR_OK:
             raise CrucibleError(rc, "cannot write " + path)
 
+    def write_image(self, path, img):
+        """P3 (.ppm, the reference's format), P6 (.pbm6 / .p6.ppm) or PNG by extension; same bytes per channel."""
+        img = np.ascontiguousarray(img)
+        rt = A.CR_REAL_F64 if img.dtype == np.float64 else A.CR_REAL_F32
+        fn = self.lib.cr_write_png if path.endswith(".png") else (self.lib.cr_write_ppm_binary if path.endswith(".p6.ppm") else self.lib.cr_write_ppm)
+        rc = fn(path.encode(), img.ctypes.data_as(C.c_void_p), rt, img.shape[1], img.shape[0])
+        if rc != A.CR_OK:
+            raise CrucibleError(rc, "cannot write " + path)
+
 
 def quantize_rgb8(img):
     """impl Display for Color (reference src/utils.rs:422-437) over a whole image -> uint8 (H, W, 3)."""

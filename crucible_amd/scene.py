@@ -155,8 +155,10 @@ def build_asset_path(asset_filename):
     raise FileNotFoundError("Could not find the asset " + asset_filename)
 
 
-def load_obj(file, scale, shift, mat):
-    """obj_loader.rs:21-143: `v`/`f` lines only, 1-based, triangles only, scale*p + shift."""
+def load_obj(file, scale, shift, mat, strict=True):
+    """obj_loader.rs:21-143: `v`/`f` lines only, 1-based, triangles only, scale*p + shift.
+    strict=False (not in the reference) additionally tolerates comments, `vn`/`vt`/`o`/`g`/`s`/
+    `usemtl`/`mtllib` lines, `v/vt/vn` face corners, negative indices and polygons (fan-triangulated)."""
     path = build_asset_path(file)
     if not path.endswith(".obj"):
         raise ValueError("Expected an obj file.")
@@ -167,14 +169,22 @@ def load_obj(file, scale, shift, mat):
             if not parts:
                 continue
             if parts[0] == "v":
-                if len(parts) != 4:
+                if len(parts) != 4 and (strict or len(parts) < 4):
                     raise ValueError("Invalid number of coordinates for a vertex")
-                verts.append(tuple(float(x) for x in parts[1:]))
+                verts.append(tuple(float(x) for x in parts[1:4]))
             elif parts[0] == "f":
-                if len(parts) != 4:
-                    raise ValueError("The asset loader only supports triangularized images")
-                faces.append(tuple(int(x) for x in parts[1:]))
-            else:
+                if strict:
+                    if len(parts) != 4:
+                        raise ValueError("The asset loader only supports triangularized images")
+                    faces.append(tuple(int(x) for x in parts[1:]))
+                else:
+                    idx = [int(c.split("/")[0]) for c in parts[1:]]
+                    idx = [i if i > 0 else len(verts) + 1 + i for i in idx]
+                    if len(idx) < 3:
+                        raise ValueError("a face needs at least three corners")
+                    for k in range(1, len(idx) - 1):
+                        faces.append((idx[0], idx[k], idx[k + 1]))
+            elif strict or not (parts[0].startswith("#") or parts[0] in ("vn", "vt", "vp", "o", "g", "s", "usemtl", "mtllib", "l")):
                 raise ValueError("Unsupported OBJ file")
     verts = [tuple(scale * p[k] + shift[k] for k in range(3)) for p in verts]
     return [Triangle(verts[f[0] - 1], verts[f[1] - 1], verts[f[2] - 1], mat) for f in faces]
@@ -305,9 +315,9 @@ class Scene:
         element.id = self._vend_id(alias, "Sphere" if isinstance(element, Sphere) else "Triangle")
         self.elements.append(element)
 
-    def load_asset(self, asset_path, alias, scale, shift, mat):
+    def load_asset(self, asset_path, alias, scale, shift, mat, strict=True):
         mesh_id = self._vend_id(alias, "TriangleMesh")
-        for t in load_obj(asset_path, scale, shift, mat):
+        for t in load_obj(asset_path, scale, shift, mat, strict=strict):
             t.id = mesh_id
             self.elements.append(t)
 

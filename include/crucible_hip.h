@@ -266,6 +266,13 @@ CR_API void* cr_stream(CrHandle* h);
 CR_API int32_t cr_write_ppm(const char* path, const void* rgb, int32_t real_type,
                      int32_t image_width, int32_t image_height);
 
+/* SURVEY 8(f) row 3 -- faster frame output than the reference's ASCII P3, same bytes per channel as
+ * `impl Display for Color`: binary PPM (P6) and 8-bit RGB PNG (what BASELINE.json's north_star names). */
+CR_API int32_t cr_write_ppm_binary(const char* path, const void* rgb, int32_t real_type,
+                                   int32_t image_width, int32_t image_height);
+CR_API int32_t cr_write_png(const char* path, const void* rgb, int32_t real_type,
+                            int32_t image_width, int32_t image_height);
+
 /* Quantise means to the bytes Display would print (3 per pixel); no file. */
 CR_API int32_t cr_quantize_rgb8(const void* rgb, int32_t real_type, int64_t n_pixels, uint8_t* out);
 

@@ -136,6 +136,17 @@ def test_obj_loader(tmp_path, monkeypatch):   # obj_loader.rs:66-143
         load_obj("quad.obj", 1.0, (0, 0, 0), None)           # triangles only
 
 
+def test_obj_loader_tolerant_mode(tmp_path, monkeypatch):   # SURVEY 8(f) row 4; the reference panics on all of these
+    (tmp_path / "m.obj").write_text("# comment\nmtllib a.mtl\no thing\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\n"
+                                    "s off\nusemtl m\nf 1/1/1 2/1/1 3/1/1 4/1/1\nf -4 -3 -2\n")
+    monkeypatch.setenv("ASSET_DIR", str(tmp_path) + "/")
+    with pytest.raises(ValueError):
+        load_obj("m.obj", 1.0, (0, 0, 0), None)
+    tris = load_obj("m.obj", 1.0, (0, 0, 0), None, strict=False)
+    assert [(t.a, t.b, t.c) for t in tris] == [((0, 0, 0), (1, 0, 0), (1, 1, 0)), ((0, 0, 0), (1, 1, 0), (0, 1, 0)),
+                                               ((0, 0, 0), (1, 0, 0), (1, 1, 0))]
+
+
 def test_teapot_asset_loads():
     sc = load_teapot(1, image_width=32, samples=1)
     assert len(sc.elements) == 6320 + 1     # assets/teapot.obj: 3644 v / 6320 f, + ground
@@ -162,6 +173,26 @@ def test_ppm_writer_and_quantiser(hiplib, tmp_path):
     q = np.zeros((1, 3), dtype=np.uint8)
     hiplib.cr_quantize_rgb8(nan.ctypes.data_as(C.c_void_p), A.CR_REAL_F64, 1, q.ctypes.data_as(C.c_void_p))
     assert q.tolist() == [[0, 0, 255]]                       # `as u32` saturates, NaN -> 0; 255*sqrt(2) = 360 -> byte clamp
+
+
+def test_png_and_binary_ppm_carry_the_same_bytes(hiplib, tmp_path):
+    """P6 and PNG output quantise exactly like the P3 writer."""
+    from PIL import Image
+    rs = np.random.RandomState(4)
+    img = rs.uniform(0, 1, size=(37, 53, 3))
+    img[0, 0] = (0.529, 0.616, 0.730)
+    expect = (255.0 * np.sqrt(img)).astype(np.uint8)
+    for dtype, rt in ((np.float64, A.CR_REAL_F64), (np.float32, A.CR_REAL_F32)):
+        a = img.astype(dtype)
+        exp = (255.0 * np.sqrt(a.astype(np.float64))).astype(np.uint8)
+        png, p6 = str(tmp_path / f"o{rt}.png"), str(tmp_path / f"o{rt}.p6.ppm")
+        assert hiplib.cr_write_png(png.encode(), a.ctypes.data_as(C.c_void_p), rt, 53, 37) == A.CR_OK
+        assert hiplib.cr_write_ppm_binary(p6.encode(), a.ctypes.data_as(C.c_void_p), rt, 53, 37) == A.CR_OK
+        assert np.array_equal(np.asarray(Image.open(png).convert("RGB")), exp)
+        raw = open(p6, "rb").read()
+        assert raw.startswith(b"P6\n53 37\n255\n") and np.array_equal(np.frombuffer(raw[len(b"P6\n53 37\n255\n"):], dtype=np.uint8).reshape(37, 53, 3), exp)
+    assert tuple(expect[0, 0]) == (185, 200, 217)
+    assert hiplib.cr_write_png(b"/nonexistent_dir/x.png", img.ctypes.data_as(C.c_void_p), A.CR_REAL_F64, 53, 37) == A.CR_ERR_IO
 
 
 def test_procedural_sky_is_seeded():
