@@ -442,8 +442,12 @@ CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<re
 
         V3<real> att = mk<real>(0, 0, 0), ndir = rd;
         bool some;
+        // Lambertian and Metal both begin their draws with random_unit_vector() (lambertian.rs:41,
+        // metal.rs:31): one shared pass of the rejection loop serves both groups of lanes
+        V3<real> ruv = mk<real>(0, 0, 0);
+        if (m.kind != 2) ruv = random_unit_vector<real>(rng);
         if (m.kind == 0) {                                  // lambertian.rs:40-61
-            V3<real> dir = add(n, random_unit_vector<real>(rng));
+            V3<real> dir = add(n, ruv);
             real tol = real(1e-8);
             if (r_abs(dir.x) < tol && r_abs(dir.y) < tol && r_abs(dir.z) < tol) dir = n;
             V3<real> tc;
@@ -455,7 +459,7 @@ CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<re
             some = rng_uniform<real>(rng) <= m.param;
         } else if (m.kind == 1) {                           // metal.rs:29-42
             V3<real> refl = reflect(rd, n);
-            refl = add(unit(refl), scale(m.param, random_unit_vector<real>(rng)));
+            refl = add(unit(refl), scale(m.param, ruv));
             att = mk<real>(m.albedo[0], m.albedo[1], m.albedo[2]);
             ndir = refl;
             some = dot(refl, n) > real(0);
