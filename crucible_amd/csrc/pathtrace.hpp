@@ -103,8 +103,13 @@ CR_HD uint64_t mix64(uint64_t z) {
 CR_HD uint64_t rng_key(uint64_t seed_mixed, uint32_t pixel, uint32_t sample) {
     return mix64(seed_mixed ^ (((uint64_t)pixel << 32) | (uint64_t)sample));
 }
-CR_HD float u01(uint64_t u, float) { return (float)(u >> 40) * 0x1.0p-24f; }
-CR_HD double u01(uint64_t u, double) { return (double)(u >> 11) * 0x1.0p-53; }
+// The conversions go through 32-bit words (exact: 24 resp. 21+32 significant bits), which is much
+// cheaper on the GPU than the generic u64 -> float sequence and yields the same value.
+CR_HD float u01(uint64_t u, float) { return (float)(uint32_t)(u >> 40) * 0x1.0p-24f; }
+CR_HD double u01(uint64_t u, double) {
+    const uint64_t v = u >> 11;
+    return ((double)(uint32_t)(v >> 32) * 4294967296.0 + (double)(uint32_t)v) * 0x1.0p-53;
+}
 template <typename real> CR_HD real rng_uniform(uint64_t& s) { s += RNG_GAMMA; return u01(mix64(s), real(0)); }
 template <typename real> CR_HD real rng_range(uint64_t& s, real lo, real hi) { return lo + (hi - lo) * rng_uniform<real>(s); }
 
