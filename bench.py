@@ -189,6 +189,13 @@ def main():
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        valu = None
+        vpath = os.path.join(ROOT, "profiles", "valu.json")
+        if os.path.exists(vpath):
+            try:
+                valu = json.load(open(vpath)).get(f"{args.workload}_{W}x{H}_spp{s_count}_{args.real}")
+            except Exception:
+                valu = None
         try:
             metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
         except Exception:
@@ -209,6 +216,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(B),
                          "counters_per_launch": {k: st[k] for k in ("samples", "segments", "node_tests", "prim_tests",
                                                                     "texel_fetches")}},
+            "valu": valu,   # VALU busy vs the measured issue peak and lane utilisation, from the committed PMC passes (or null)
             "kernel_msamples_per_s": round(W * H * s_count / (k_ms * 1e-3) / 1e6, 2) if k_ms > 0 else None,
         }
         if world == 1 and not args.no_cpu_baseline and args.workload != "million":
