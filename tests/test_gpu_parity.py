@@ -194,6 +194,17 @@ def test_scene_in_global_memory(renderer, oracles, rt, tag):
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+def test_million_primitives_full_scale(renderer, oracles, rt, tag):
+    """BASELINE config 4's scene at full size (1 000 001 spheres, 1 048 575 wrappers, depth-20 tree; parallel builder,
+    top levels in LDS, the rest through L2) at a small frame: bit-exact against the oracle's recursive tree."""
+    sc = million_spheres(1, scene_seed=1, half_extent=500, image_width=64, samples=2)
+    img, st = gpu_render(renderer, sc, rt)
+    ref, rst = oracles[rt].render_image(sc, seed=SEED)
+    assert st["bvh_entries"] == rst["bvh_entries"] == 1048575 and st["scene_in_lds"] == 2
+    assert_exact(img, st, ref, rst)
+
+
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
 def test_teapot_with_environment_map(renderer, oracles, rt, tag):
     """BASELINE config 3 at test size: 6320 triangles + ground sphere + spherical sky."""
     sc = load_teapot(1, image_width=96, samples=3, sky=procedural_sky(256, 128))
