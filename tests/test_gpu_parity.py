@@ -317,6 +317,32 @@ def test_render_scene_writes_reference_ppm(renderer, oracles, tmp_path):
     assert np.array_equal(got, (255.0 * np.sqrt(ref)).astype(np.int64).reshape(-1, 3))
 
 
+def test_nan_policy_matches_reference_panic(renderer, oracles):
+    """look_from == look_at makes w = unit(0) = NaN, so every pixel mean is NaN: the reference panics in Color::new
+    (ray_casting.rs:172, utils.rs:345-350); the oracle counts the pixels, the library returns CR_ERR_NAN."""
+    sc = scenes.few_spheres(2, width=24, samples=2)
+    sc.scene_cam.look_from((1.0, 2.0, 3.0))
+    sc.scene_cam.look_at((1.0, 2.0, 3.0))
+    _, ost = oracles[A.CR_REAL_F32].render_image(sc, seed=SEED)
+    assert ost["nan_pixels"] == 24 * 13
+    renderer.upload_scene(sc.flatten())
+    with pytest.raises(CrucibleError) as e:
+        renderer.render(sc.scene_cam, seed=SEED, real_type=A.CR_REAL_F32)
+    assert e.value.code == A.CR_ERR_NAN
+    sums, _ = renderer.render(sc.scene_cam, seed=SEED, real_type=A.CR_REAL_F32, output_sum=True)   # raw sums are not checked
+    assert np.isnan(sums).all()
+
+
+def test_size_limits(renderer):
+    sc = scenes.few_spheres(1)
+    renderer.upload_scene(sc.flatten())
+    cam = sc.scene_cam
+    cam.image_width, cam.image_height = 16384, 8192          # 2^27 pixels > the 2^26 limit
+    with pytest.raises(CrucibleError) as e:
+        renderer.render_device(cam, 1, seed=1)
+    assert e.value.code == A.CR_ERR_INVALID_ARG and "too large" in str(e.value)
+
+
 def test_error_codes(renderer, hiplib):
     from crucible_amd.renderer import Renderer
     sc = scenes.few_spheres(2)
