@@ -542,10 +542,11 @@ CR_D Entry<real> fetch_entry(const Entry<real>* lds, const Entry<real>* glob, in
 // SHADE: closest hit known.
 enum : int { ST_NEED_PIXEL = 0, ST_NEED_SAMPLE = 1, ST_TRACE = 2, ST_DONE = 3, ST_WALK = 4, ST_SHADE = 5 };
 
-// Largest workgroup each scalar type may be launched with.  The launch bound caps the
-// register allocation: 1024 threads = 4 waves/SIMD = 128 VGPRs (enough for f32),
-// 512 threads = 2 waves/SIMD = 256 VGPRs (the f64 kernel needs ~200).
-template <typename real> struct MaxBlock { static constexpr int value = sizeof(real) == 4 ? 1024 : 512; };
+// Largest workgroup the kernels may be launched with.  The launch bound caps the register allocation:
+// 1024 threads = 4 waves/SIMD = 128 VGPRs.  The f32 kernel needs ~95; the f64 kernel would like ~185 and
+// spills ~46 registers to scratch under this cap, yet 4 waves/SIMD with those spills measured 7 % faster
+// than 2 waves/SIMD without (1955 vs 1830 Msamples/s on book1).
+template <typename real> struct MaxBlock { static constexpr int value = 1024; };
 
 // One lane = one pixel at a time, all of that pixel's samples in draw order (so the
 // per-pixel sum is the reference's sequential sum).  Lanes that finish a pixel pull the
