@@ -207,7 +207,7 @@ def main():
             "config": {"workload": wl.format(W=W, H=H, spp=spp, d=cam.max_depth),
                        "image": [W, H], "spp": spp, "max_depth": cam.max_depth, "scene_seed": scene_seed, "rng_seed": seed,
                        "primitives": len(scene.elements), "bvh_entries": st["bvh_entries"],
-                       "scene_in_lds": bool(st["scene_in_lds"]),
+                       "scene_residency": {0: "L2", 1: "whole scene in LDS", 2: "BVH top levels in LDS"}.get(st["scene_in_lds"]),
                        "parallelism": "1 GPU" if world == 1 else (f"frame-shard x{world}, no collective" if frame_sharded else
                                                                      f"spp-shard x{world} + {args.backend} reduce of the RGB sums")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

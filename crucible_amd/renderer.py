@@ -56,7 +56,6 @@ class Renderer:
         if rc != A.CR_OK:
             raise CrucibleError(rc, (self.lib.cr_last_error(None) or b"").decode())
         self.h = h
-        self._flat = None
 
     def _check(self, rc):
         if rc != A.CR_OK:

@@ -217,7 +217,7 @@ typedef struct CrStats {
     double kernel_ms;       /* HIP-event time of the render kernel(s) on the handle's stream */
     double upload_ms;
     int32_t bvh_entries;
-    int32_t scene_in_lds;
+    int32_t scene_in_lds;   /* 0: scene read through L2; 1: whole scene staged in LDS; 2: top levels of the BVH in LDS */
 } CrStats;
 
 typedef struct CrHandle CrHandle;
