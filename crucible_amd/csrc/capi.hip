@@ -230,6 +230,7 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
         const CrPrimitive& p = h->prims[vis[i]];
         Prim<real>& q = src[i];
         for (int k = 0; k < 9; k++) q.g[k] = (real)p.v[k];
+        if (p.kind == CR_PRIM_SPHERE) q.g[4] = real(1) / q.g[3];    // 1/radius, used for the hit normal of static spheres
         q.kind_mat = (p.kind & 1) | (p.material << 1);
         q.key_first = p.key_first; q.key_count = p.key_count;
         any_keys |= p.key_count > 0;
@@ -274,6 +275,12 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
             const CrTexture& t = h->textures[m.texture];
             if (t.kind == CR_TEX_SOLID) for (int k = 0; k < 3; k++) o.albedo[k] = (real)t.color[k];
             else o.tex = tex_remap[m.texture];
+            o.aux = real(1) / r_abs(o.param);                       // Color / f64: (1.0 / rhs.abs()) * c
+        } else if (m.kind == CR_MAT_DIELECTRIC) {
+            auto r0 = [](real ri) { real q = (real(1) - ri) / (real(1) + ri); return q * q; };   // dielectric.rs:21-23
+            o.albedo[0] = real(1) / o.param;                        // ri for a front-face hit (dielectric.rs:33-37)
+            o.albedo[1] = r0(o.albedo[0]);
+            o.albedo[2] = r0(o.param);
         }
     }
     std::vector<Tex<real>> texs;

@@ -148,12 +148,15 @@ template <typename real> struct alignas(16) Prim {
     CR_HD int32_t mat() const { return kind_mat >> 1; }
 };
 template <typename real> struct alignas(16) Mat {
-    real albedo[3];   // metal albedo, or the lambertian's colour when its texture is solid
+    real albedo[3];   // metal albedo | lambertian colour when its texture is solid | dielectric: {1/ior, r0(1/ior), r0(ior)}
     real param;       // scatter_prob | fuzz | refraction_index
     int32_t kind;
     int32_t tex;      // lambertian: texture index, or -1 when albedo[] already holds the solid colour
-    int32_t pad0, pad1;
+    real aux;         // lambertian: 1/|scatter_prob|, the factor Color / f64 multiplies by (utils.rs:599-607)
 };
+// Per-material / per-primitive values the reference recomputes at every hit are computed once at upload with
+// the same IEEE operations: 1/radius for static spheres (Prim::g[4]; sphere.rs:97 `/ radius` = (1/radius)*v),
+// 1/scatter_prob, 1/ior and Schlick's r0 = ((1-ri)/(1+ri))^2 for both orientations (dielectric.rs:21-38).
 template <typename real> struct alignas(16) Tex {
     real color[3];
     real inv_scale;
@@ -423,8 +426,10 @@ CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<re
         }
         if (p.kind() == 0) {
             real g0 = p.g[0], g1 = p.g[1], g2 = p.g[2], g3 = p.g[3];
-            if (ANIM && p.key_count) timeline_eval(A.keys + p.key_first, p.key_count, rtime, g0, g1, g2, g3);
-            n = divs(sub(loc, mk<real>(g0, g1, g2)), g3);   // sphere.rs:97
+            if (ANIM && p.key_count) {
+                timeline_eval(A.keys + p.key_first, p.key_count, rtime, g0, g1, g2, g3);
+                n = divs(sub(loc, mk<real>(g0, g1, g2)), g3);   // sphere.rs:97
+            } else n = scale(p.g[4], sub(loc, mk<real>(g0, g1, g2)));   // p.g[4] = 1/radius
             if (need_uv) {                                  // get_sphere_uv, sphere.rs:41-46
                 real theta = r_acos(-n.y);
                 real phi = r_atan2(-n.z, n.x) + RealTraits<real>::pi;
@@ -459,7 +464,7 @@ CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<re
             if (m.tex < 0) tc = mk<real>(m.albedo[0], m.albedo[1], m.albedo[2]);
             else if (need_uv) tc = image_lookup(A.images, A.texels, texs[leaf_tex].image, tu, tv, c_tex);
             else tc = mk<real>(texs[leaf_tex].color[0], texs[leaf_tex].color[1], texs[leaf_tex].color[2]);
-            att = c_div(tc, m.param);
+            att = c_scale(m.aux, (m.param < real(0)) ? c_neg(tc) : tc);   // tc / scatter_prob
             ndir = dir;
             some = rng_uniform<real>(rng) <= m.param;
         } else if (m.kind == 1) {                           // metal.rs:29-42
@@ -470,14 +475,13 @@ CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<re
             some = dot(refl, n) > real(0);
         } else {                                            // dielectric.rs:30-55
             att = mk<real>(1, 1, 1);
-            real ri = front ? real(1) / m.param : m.param;
+            real ri = front ? m.albedo[0] : m.param;
             V3<real> ud = unit(rd);
             real cos_theta = -(r_fmin(dot(ud, n), real(1)));
             real sin_theta = r_sqrt(real(1) - cos_theta * cos_theta);
             bool refl = ri * sin_theta > real(1);
             if (!refl) {
-                real r0 = (real(1) - ri) / (real(1) + ri);
-                r0 = r0 * r0;
+                real r0 = front ? m.albedo[1] : m.albedo[2];
                 real x = real(1) - cos_theta;
                 real x2 = x * x;
                 real x5 = x * (x2 * x2);
