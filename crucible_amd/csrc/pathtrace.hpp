@@ -534,6 +534,84 @@ CR_D Entry<real> fetch_entry(const Entry<real>* lds, const Entry<real>* glob, in
     return glob[idx];
 }
 
+// The per-ray state of BVHWrapper::hit's walk, kept in registers so a walk can be suspended and resumed.
+template <typename real> struct WalkState {
+    V3<real> inv;        // 1 / direction
+    real dd;             // |direction|^2: Sphere::hit's `a`, the same for every sphere of the segment
+    real best_t;         // closest hit so far = the interval's max handed to the next wrapper
+    int32_t best;        // leaf-order index of that primitive, -1 = none
+    int32_t idx;         // next wrapper to visit; n_entries = walk finished
+    bool exact_box;      // an infinite 1/dir component: Aabb::hit's compare/select form is required
+};
+
+template <typename real> CR_D void walk_begin(WalkState<real>& w, V3<real> rd) {
+    w.inv = mk<real>(real(1) / rd.x, real(1) / rd.y, real(1) / rd.z);
+    // 1/dir infinite on some axis (zero or denormal component): slab distances can be NaN, where only the
+    // compare/select form reproduces Aabb::hit
+    w.exact_box = (r_abs(w.inv.x) == r_inf(real(0))) || (r_abs(w.inv.y) == r_inf(real(0))) || (r_abs(w.inv.z) == r_inf(real(0)));
+    w.dd = len2(rd);
+    w.idx = 0; w.best_t = r_inf(real(0)); w.best = -1;
+}
+
+// One round of the while-while walk for the lanes with `walking` set: step through wrappers in the reference's
+// order (left child on a box hit, skip link on a miss) until the lane reaches a leaf wrapper, runs out of wrappers
+// or has made `budget` steps (0 = unbounded); then the lanes parked on a leaf intersect its primitives together.
+// Per lane this is exactly BVHWrapper::hit's sequence (bvhwrapper.rs:96-126); the round structure only decides
+// when lanes wait for each other.
+template <typename real, int RES, bool ANIM>
+CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, const Prim<real>* prims, V3<real> ro, V3<real> rd, real rtime,
+                     WalkState<real>& w, bool walking, uint32_t budget, unsigned long long& c_node, uint32_t& c_prim) {
+    const real tmin = real(0.001);
+    const int32_t n_entries = A.n_entries;
+    int32_t leaf = -1;
+    if (walking) {
+        if (!w.exact_box) {
+            const Pair<real> ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
+            const Pair<real> ix = {w.inv.x, w.inv.x}, iy = {w.inv.y, w.inv.y}, iz = {w.inv.z, w.inv.z};
+            while (w.idx < n_entries) {
+                const Entry<real> e = fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx);
+                c_node++;
+                bool hit = box_hit_fast(e.b, ox, oy, oz, ix, iy, iz, tmin, w.best_t);
+                w.idx = (hit && e.leaf < 0) ? -e.leaf : e.skip;
+                if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
+                if (--budget == 0) break;
+            }
+        } else {
+            while (w.idx < n_entries) {
+                const Entry<real> e = fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx);
+                c_node++;
+                bool hit = box_hit(e.b, ro, w.inv, tmin, w.best_t);
+                w.idx = (hit && e.leaf < 0) ? -e.leaf : e.skip;
+                if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
+            }
+        }
+    }
+    if (leaf >= 0) {
+        int32_t first = leaf >> 1, count = (leaf & 1) + 1;
+        for (int32_t k = 0; k < count; k++) {
+            const Prim<real>& p = prims[first + k];
+            c_prim++;
+            real t;
+            bool h;
+            real g0 = p.g[0], g1 = p.g[1], g2 = p.g[2], g3 = p.g[3];
+            if (p.kind() == 0) {
+                if (ANIM && p.key_count) timeline_eval(A.keys + p.key_first, p.key_count, rtime, g0, g1, g2, g3);
+                h = sphere_t(g0, g1, g2, g3, ro, rd, w.dd, tmin, w.best_t, t);
+            } else {
+                V3<real> a = mk<real>(g0, g1, g2), b = mk<real>(g3, p.g[4], p.g[5]), c = mk<real>(p.g[6], p.g[7], p.g[8]);
+                if (ANIM && p.key_count) {
+                    real ws = real(1);
+                    timeline_eval(A.keys + p.key_first, p.key_count, rtime, a.x, a.y, a.z, ws); a = scale(ws, a); ws = real(1);
+                    timeline_eval(A.keys + p.key_first, p.key_count, rtime, b.x, b.y, b.z, ws); b = scale(ws, b); ws = real(1);
+                    timeline_eval(A.keys + p.key_first, p.key_count, rtime, c.x, c.y, c.z, ws); c = scale(ws, c);
+                }
+                h = triangle_t(a, b, c, ro, rd, tmin, w.best_t, t);
+            }
+            if (h) { w.best_t = t; w.best = first + k; }
+        }
+    }
+}
+
 // Diagnostic build (-DCR_DIAG, scripts/diag only): per-wave phase clocks and lane-occupancy sums go to
 // counters[4..15]; the product build compiles none of it.
 #ifdef CR_DIAG
@@ -601,11 +679,8 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
     uint32_t c_seg = 0, c_prim = 0, c_tex = 0;
     unsigned long long c_node = 0;
     // walk state, kept across rounds: a lane whose walk is cut short resumes where it stopped
-    V3<real> inv = mk<real>(0, 0, 0);
-    real best_t = 0, dd = 0;
-    int32_t best = -1, idx = 0;
-    bool exact_box = false;
-    const real tmin = real(0.001);
+    WalkState<real> ws;
+    ws.inv = mk<real>(0, 0, 0); ws.dd = 0; ws.best_t = 0; ws.best = -1; ws.idx = 0; ws.exact_box = false;
     const int32_t n_entries = A.n_entries;
 
     CR_DIAG_ONLY(unsigned long long d_iter = 0, d_inner = 0, d_inner_lanes = 0, d_leaf = 0, d_leaf_lanes = 0, d_t_regen = 0, d_t_trace = 0,
@@ -652,74 +727,19 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
             if (depth_left == 0) finished = true;   // ray_color: depth == 0 -> black
             else {
                 c_seg++;
-                inv = mk<real>(real(1) / rd.x, real(1) / rd.y, real(1) / rd.z);
-                // 1/dir infinite on some axis (zero or denormal component): slab distances can be NaN,
-                // where only the compare/select form reproduces Aabb::hit
-                exact_box = (r_abs(inv.x) == r_inf(real(0))) || (r_abs(inv.y) == r_inf(real(0))) || (r_abs(inv.z) == r_inf(real(0)));
-                dd = len2(rd);   // Sphere::hit's `a`, the same for every sphere of this segment
-                idx = 0; best_t = r_inf(real(0)); best = -1;
+                walk_begin(ws, rd);
                 state = n_entries > 0 ? ST_WALK : ST_SHADE;
             }
         }
-        // while-while: every lane walks its own wrappers in the reference's order (idx+1 on a box hit,
-        // skip link on a miss); a lane that reaches a leaf wrapper parks until the other walking lanes
-        // have found theirs (or run out), then the leaves are intersected together.  After each such
-        // round the wave may leave the walk if enough lanes are done: the stragglers keep idx / best and
-        // resume on the next round of the outer loop, so each lane still performs BVHWrapper::hit's
-        // exact sequence; only the interleaving with other lanes' shading changes.
+        // Rounds of the while-while walk (walk_round).  After each round the wave may leave the walk if enough
+        // lanes are done: the stragglers keep their WalkState and resume on the next round of the outer loop, so
+        // each lane still performs BVHWrapper::hit's exact sequence; only the interleaving with other lanes'
+        // shading changes.
         if (__ballot(state == ST_WALK)) {
-            const Pair<real> ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
-            const Pair<real> ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
             for (;;) {
-                int32_t leaf = -1;
-                if (state == ST_WALK) {
-                    if (!exact_box) {
-                        uint32_t budget = A.walk_round_steps;   // bounds how long lanes parked on a leaf wait for the others
-                        while (idx < n_entries) {
-                            const Entry<real> e = fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, idx);
-                            c_node++;
-                            CR_DIAG_ONLY(d_inner++; d_inner_lanes += 65536u / (unsigned)__popcll(__ballot(true));)
-                            bool hit = box_hit_fast(e.b, ox, oy, oz, ix, iy, iz, tmin, best_t);
-                            idx = (hit && e.leaf < 0) ? -e.leaf : e.skip;
-                            if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
-                            if (--budget == 0) break;
-                        }
-                    } else {
-                        while (idx < n_entries) {
-                            const Entry<real> e = fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, idx);
-                            c_node++;
-                            bool hit = box_hit(e.b, ro, inv, tmin, best_t);
-                            idx = (hit && e.leaf < 0) ? -e.leaf : e.skip;
-                            if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
-                        }
-                    }
-                }
-                if (leaf >= 0) {
-                    CR_DIAG_ONLY(d_leaf++; d_leaf_lanes += 65536u / (unsigned)__popcll(__ballot(true));)
-                    int32_t first = leaf >> 1, count = (leaf & 1) + 1;
-                    for (int32_t k = 0; k < count; k++) {
-                        const Prim<real>& p = prims[first + k];
-                        c_prim++;
-                        real t;
-                        bool h;
-                        real g0 = p.g[0], g1 = p.g[1], g2 = p.g[2], g3 = p.g[3];
-                        if (p.kind() == 0) {
-                            if (ANIM && p.key_count) timeline_eval(A.keys + p.key_first, p.key_count, rtime, g0, g1, g2, g3);
-                            h = sphere_t(g0, g1, g2, g3, ro, rd, dd, tmin, best_t, t);
-                        } else {
-                            V3<real> a = mk<real>(g0, g1, g2), b = mk<real>(g3, p.g[4], p.g[5]), c = mk<real>(p.g[6], p.g[7], p.g[8]);
-                            if (ANIM && p.key_count) {
-                                real w = real(1);
-                                timeline_eval(A.keys + p.key_first, p.key_count, rtime, a.x, a.y, a.z, w); a = scale(w, a); w = real(1);
-                                timeline_eval(A.keys + p.key_first, p.key_count, rtime, b.x, b.y, b.z, w); b = scale(w, b); w = real(1);
-                                timeline_eval(A.keys + p.key_first, p.key_count, rtime, c.x, c.y, c.z, w); c = scale(w, c);
-                            }
-                            h = triangle_t(a, b, c, ro, rd, tmin, best_t, t);
-                        }
-                        if (h) { best_t = t; best = first + k; }
-                    }
-                }
-                if (state == ST_WALK && idx >= n_entries) state = ST_SHADE;
+                CR_DIAG_ONLY(d_leaf++;)
+                walk_round<real, RES, ANIM>(A, lds_entries, prims, ro, rd, rtime, ws, state == ST_WALK, A.walk_round_steps, c_node, c_prim);
+                if (state == ST_WALK && ws.idx >= n_entries) state = ST_SHADE;
                 const uint64_t walking = __ballot(state == ST_WALK);
                 if (!walking || 64u - (uint32_t)__popcll(walking) >= A.walk_exit_lanes) break;
             }
@@ -729,7 +749,7 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
         CR_DIAG_ONLY({ unsigned long long t = __builtin_readcyclecounter(); d_t_trace += t - d_t0; d_t0 = t; d_shade_lanes += __popcll(__ballot(tracing)); })
         // ---------------- shade
         if (tracing) {
-            finished = shade<real, ANIM>(A, prims, mats, texs, ro, rd, rtime, rng, depth_left, stack_n, best_t, best,
+            finished = shade<real, ANIM>(A, prims, mats, texs, ro, rd, rtime, rng, depth_left, stack_n, ws.best_t, ws.best,
                                          A.n_threads, gtid, c_tex, col);
             state = ST_TRACE;   // scattered: a fresh ray to walk (overwritten below when the path finished)
         }

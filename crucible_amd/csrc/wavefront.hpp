@@ -181,21 +181,17 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) wf_extend_kernel(const 
     uint32_t cn = 0, ce = 0;   // this wave's private range of slots to scan
     bool drained = false;
     const int32_t n_entries = A.n_entries;
-    const real tmin = real(0.001);
 
     bool has_ray = false;
     uint32_t slot = 0;
-    V3<real> ro = mk<real>(0, 0, 0), rd = mk<real>(0, 0, 1), inv = mk<real>(0, 0, 0);
-    Pair<real> ox = {0, 0}, oy = {0, 0}, oz = {0, 0}, ix = {0, 0}, iy = {0, 0}, iz = {0, 0};
-    real rtime = 0, dd = 0, best_t = 0;
-    bool exact_box = false;
-    int32_t idx = 0, best = -1;
+    V3<real> ro = mk<real>(0, 0, 0), rd = mk<real>(0, 0, 1);
+    real rtime = 0;
+    WalkState<real> ws;
+    ws.inv = mk<real>(0, 0, 0); ws.dd = 0; ws.best_t = 0; ws.best = -1; ws.idx = 0; ws.exact_box = false;
     uint32_t c_prim = 0;
     unsigned long long c_node = 0;
-    CR_DIAG_ONLY(unsigned long long d_w = 0, d_leafw = 0, d_leafl = 0, d_t_refill = 0, d_t_walk = 0, d_t_leaf = 0, d_rounds = 0, d_t0 = __builtin_readcyclecounter(); const unsigned long long d_begin = d_t0;)
 
     for (;;) {
-        CR_DIAG_ONLY(d_rounds++; d_t0 = __builtin_readcyclecounter();)
         // ---- refill: lanes without a ray scan the wave's private slot range for pending rays; the range is
         // topped up WF_CHUNK slots at a time with one atomic
         for (;;) {
@@ -215,12 +211,7 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) wf_extend_kernel(const 
                     ro = mk<real>(W.ray[slot], W.ray[N + slot], W.ray[2 * (size_t)N + slot]);
                     rd = mk<real>(W.ray[3 * (size_t)N + slot], W.ray[4 * (size_t)N + slot], W.ray[5 * (size_t)N + slot]);
                     if (ANIM) rtime = W.ray[6 * (size_t)N + slot];
-                    inv = mk<real>(real(1) / rd.x, real(1) / rd.y, real(1) / rd.z);
-                    exact_box = (r_abs(inv.x) == r_inf(real(0))) || (r_abs(inv.y) == r_inf(real(0))) || (r_abs(inv.z) == r_inf(real(0)));
-                    ox = Pair<real>{ro.x, ro.x}; oy = Pair<real>{ro.y, ro.y}; oz = Pair<real>{ro.z, ro.z};
-                    ix = Pair<real>{inv.x, inv.x}; iy = Pair<real>{inv.y, inv.y}; iz = Pair<real>{inv.z, inv.z};
-                    dd = len2(rd);
-                    idx = 0; best_t = r_inf(real(0)); best = -1;
+                    walk_begin(ws, rd);
                     has_ray = true;
                 }
             }
@@ -228,62 +219,11 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) wf_extend_kernel(const 
             cn += want < avail ? want : avail;
         }
         if (__ballot(has_ray) == 0) break;
-        CR_DIAG_ONLY({ unsigned long long t = __builtin_readcyclecounter(); d_t_refill += t - d_t0; d_t0 = t; })
-
-        // ---- walk wrappers until this lane's next leaf (or the end of its ray)
-        int32_t leaf = -1;
-        if (has_ray) {
-            if (!exact_box) {
-                while (idx < n_entries) {
-                    const Entry<real> e = fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, idx);
-                    c_node++;
-                    CR_DIAG_ONLY(d_w += 65536u / (unsigned)__popcll(__ballot(true));)
-                    bool hit = box_hit_fast(e.b, ox, oy, oz, ix, iy, iz, tmin, best_t);
-                    idx = (hit && e.leaf < 0) ? -e.leaf : e.skip;
-                    if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
-                }
-            } else {
-                while (idx < n_entries) {
-                    const Entry<real> e = fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, idx);
-                    c_node++;
-                    bool hit = box_hit(e.b, ro, inv, tmin, best_t);
-                    idx = (hit && e.leaf < 0) ? -e.leaf : e.skip;
-                    if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
-                }
-            }
-        }
-        CR_DIAG_ONLY({ unsigned long long t = __builtin_readcyclecounter(); d_t_walk += t - d_t0; d_t0 = t; })
-        // ---- leaves
-        if (leaf >= 0) {
-            CR_DIAG_ONLY(d_leafl++; d_leafw += 65536u / (unsigned)__popcll(__ballot(true));)
-            int32_t first = leaf >> 1, count = (leaf & 1) + 1;
-            for (int32_t k = 0; k < count; k++) {
-                const Prim<real>& p = prims[first + k];
-                c_prim++;
-                real t;
-                bool h;
-                real g0 = p.g[0], g1 = p.g[1], g2 = p.g[2], g3 = p.g[3];
-                if (p.kind() == 0) {
-                    if (ANIM && p.key_count) timeline_eval(A.keys + p.key_first, p.key_count, rtime, g0, g1, g2, g3);
-                    h = sphere_t(g0, g1, g2, g3, ro, rd, dd, tmin, best_t, t);
-                } else {
-                    V3<real> a = mk<real>(g0, g1, g2), b = mk<real>(g3, p.g[4], p.g[5]), c = mk<real>(p.g[6], p.g[7], p.g[8]);
-                    if (ANIM && p.key_count) {
-                        real w = real(1);
-                        timeline_eval(A.keys + p.key_first, p.key_count, rtime, a.x, a.y, a.z, w); a = scale(w, a); w = real(1);
-                        timeline_eval(A.keys + p.key_first, p.key_count, rtime, b.x, b.y, b.z, w); b = scale(w, b); w = real(1);
-                        timeline_eval(A.keys + p.key_first, p.key_count, rtime, c.x, c.y, c.z, w); c = scale(w, c);
-                    }
-                    h = triangle_t(a, b, c, ro, rd, tmin, best_t, t);
-                }
-                if (h) { best_t = t; best = first + k; }
-            }
-        }
-        CR_DIAG_ONLY({ unsigned long long t = __builtin_readcyclecounter(); d_t_leaf += t - d_t0; d_t0 = t; })
+        walk_round<real, RES, ANIM>(A, lds_entries, prims, ro, rd, rtime, ws, has_ray, 0u, c_node, c_prim);
         // ---- a ray with no wrappers left is done: hand its hit to the logic kernel
-        if (has_ray && idx >= n_entries) {
-            W.hit_t[slot] = best_t;
-            W.hit_prim[slot] = best;
+        if (has_ray && ws.idx >= n_entries) {
+            W.hit_t[slot] = ws.best_t;
+            W.hit_prim[slot] = ws.best;
             has_ray = false;
         }
     }
@@ -293,14 +233,6 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) wf_extend_kernel(const 
         atomicAdd((unsigned long long*)&A.counters[1], s1);
         atomicAdd((unsigned long long*)&A.counters[2], s2);
     }
-    CR_DIAG_ONLY(
-        unsigned long long w = d_w, lw = d_leafw, ll = d_leafl;
-        for (int off = 32; off > 0; off >>= 1) { w += __shfl_down(w, off); lw += __shfl_down(lw, off); ll += __shfl_down(ll, off); }
-        if (lane == 0) {
-            unsigned long long* c = (unsigned long long*)A.counters;
-            atomicAdd(&c[4], d_rounds); atomicAdd(&c[5], w >> 16); atomicAdd(&c[6], ll); atomicAdd(&c[7], lw >> 16);
-            atomicAdd(&c[8], d_t_refill); atomicAdd(&c[9], d_t_walk); atomicAdd(&c[10], d_t_leaf); atomicAdd(&c[11], __builtin_readcyclecounter() - d_begin);
-        })
 }
 
 // average_samples' running sum (ray_casting.rs:161-165): samples of the batch are added in sample order.
