@@ -7,6 +7,7 @@
 #include "../../include/crucible_hip.h"
 #include "pathtrace.hpp"
 #include "wavefront.hpp"
+#include "queue.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -75,7 +76,8 @@ struct CrHandle {
     uint32_t* wf_ring_host = nullptr;   // host-mapped ring the extend kernel reports its queue length into
     uint32_t* wf_ring_dev = nullptr;
     hipEvent_t wf_ev[8] = {};
-    int pipeline = 0;                   // 0 = megakernel (default), 1 = wavefront (CRUCIBLE_PIPELINE=mega|wavefront)
+    int pipeline = 0;                   // 0 = megakernel (default), 1 = wavefront kernels, 2 = LDS-queue megakernel (CRUCIBLE_PIPELINE=mega|wavefront|queue)
+    int queue_walk_waves = 9, queue_min_batch = 48, queue_patience = 64;
     uint32_t wf_slots = 1u << 21;
     size_t wf_sample_bytes = (size_t)1600 << 20;
     int wf_last_iterations = 0;
@@ -87,6 +89,7 @@ struct CrHandle {
     int walk_round_steps = 12;         // 0 = a round lasts until every walking lane found a leaf or ran out (measured: 12)
     int walk_exit_lanes = 56;          // leave the walk phase once this many lanes are not walking (64 = wait for all; measured: 56)
     int last_block = 0, last_grid = 0;
+    bool check_abort = false;          // the last launch was a queue kernel whose abort word has not been read yet
 };
 
 namespace {
@@ -394,6 +397,52 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
 }
 
 
+// ---------------------------------------------------------------- LDS-queue megakernel (queue.hpp)
+template <typename real, int RES, bool ANIM>
+int32_t launch_queue(CrHandle* h, const KernelArgs<real>& args_in, size_t scene_lds_bytes, CrStats* stats) {
+    KernelArgs<real> args = args_in;
+    auto kern = queue_kernel<real, RES, ANIM>;
+    const size_t lds_bytes = ((scene_lds_bytes + 15) & ~(size_t)15) + queue_state_bytes<real>();
+    HIP_TRY(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int per_cu = 0;
+    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, (int)QK_SLOTS, lds_bytes));
+    if (per_cu < 1) return fail(h, CR_ERR_HIP, "queue kernel does not fit on a CU");
+    const uint32_t total_work = args.tiles_x * args.tiles_y * 64u;
+    uint32_t grid = (uint32_t)(h->n_cus * per_cu);
+    const uint32_t need_blocks = (total_work + QK_SLOTS - 1) / QK_SLOTS;
+    if (grid > need_blocks) grid = need_blocks;
+    if (grid < 1) grid = 1;
+    args.n_threads = grid * QK_SLOTS;
+    args.queue_walk_waves = (uint32_t)h->queue_walk_waves;
+    args.queue_min_batch = (uint32_t)h->queue_min_batch; args.queue_patience = (uint32_t)h->queue_patience;
+    HIP_TRY(h, h->att_stack.ensure((size_t)3 * (size_t)std::max(1, args.max_depth) * args.n_threads * sizeof(real)));
+    args.att_stack = (real*)h->att_stack.p;
+    HIP_TRY(h, hipMemsetAsync(h->work_counter.p, 0, 4, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 16 * sizeof(uint64_t), h->stream));
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(QK_SLOTS), lds_bytes, h->stream, args);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    h->last_block = (int)QK_SLOTS; h->last_grid = (int)grid; h->check_abort = true;
+    if (stats) {
+        HIP_TRY(h, hipEventSynchronize(h->ev1));
+        float ms = 0;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        uint64_t c[5];
+        HIP_TRY(h, hipMemcpy(c, h->counters.p, sizeof c, hipMemcpyDeviceToHost));
+        h->check_abort = false;
+        if (c[4]) return fail(h, CR_ERR_HIP, "queue pipeline: a wave timed out waiting on an LDS queue (image incomplete)");
+        memset(stats, 0, sizeof *stats);
+        stats->kernel_ms = ms;
+        stats->segments = c[0]; stats->node_tests = c[1]; stats->prim_tests = c[2]; stats->texel_fetches = c[3];
+        stats->samples = (uint64_t)args.cam.W * (uint64_t)args.cam.H * (uint64_t)(args.sample_end - args.sample_begin);
+        stats->upload_ms = h->upload_ms;
+        stats->bvh_entries = args.n_entries;
+        stats->scene_in_lds = RES;
+    }
+    return CR_OK;
+}
+
 // ---------------------------------------------------------------- wavefront pipeline driver
 template <typename real, int RES, bool ANIM>
 int32_t wf_extend_config(CrHandle* h, size_t lds_bytes, int& block, int& grid) {
@@ -600,6 +649,19 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
 
     const bool anim = ds.animated || c.animated;
     if (h->pipeline == 1) return render_wavefront<real>(h, a, ds, anim, stats);
+    if (h->pipeline == 2) {   // LDS-queue megakernel when scene + slot arrays fit in LDS, else the plain megakernel below
+        const size_t budget = 160 * 1024, state = queue_state_bytes<real>();
+        if (ds.n_entries > 0 && ds.lds_bytes + 16 + state <= budget) {
+            a.lds_entries = ds.n_entries;
+            return anim ? launch_queue<real, RES_LDS, true>(h, a, ds.lds_bytes, stats) : launch_queue<real, RES_LDS, false>(h, a, ds.lds_bytes, stats);
+        }
+        if (ds.n_entries > 0 && state + 16 * 1024 <= budget) {
+            const size_t top_bytes = std::min(h->lds_top_bytes, (budget - state - 64) & ~(size_t)1023);
+            a.lds_entries = (int32_t)std::min<size_t>((size_t)ds.n_entries, top_bytes / sizeof(Entry<real>));
+            const size_t bytes = (size_t)a.lds_entries * sizeof(Entry<real>);
+            return anim ? launch_queue<real, RES_TOP, true>(h, a, bytes, stats) : launch_queue<real, RES_TOP, false>(h, a, bytes, stats);
+        }
+    }
     if (ds.n_entries > 0 && ds.lds_bytes <= h->lds_limit) {
         a.lds_entries = ds.n_entries;
         return anim ? launch<real, RES_LDS, true>(h, a, ds.lds_bytes, stats) : launch<real, RES_LDS, false>(h, a, ds.lds_bytes, stats);
@@ -675,7 +737,10 @@ int32_t cr_create(int32_t device_id, CrHandle** out) {
     if (const char* s = getenv("CRUCIBLE_BLOCK")) h->block_override = atoi(s);
     if (const char* s = getenv("CRUCIBLE_WALK_ROUND")) h->walk_round_steps = std::max(0, atoi(s));
     if (const char* s = getenv("CRUCIBLE_WALK_EXIT")) h->walk_exit_lanes = std::min(64, std::max(1, atoi(s)));
-    if (const char* s = getenv("CRUCIBLE_PIPELINE")) h->pipeline = (strcmp(s, "mega") == 0) ? 0 : 1;
+    if (const char* s = getenv("CRUCIBLE_PIPELINE")) h->pipeline = strcmp(s, "mega") == 0 ? 0 : (strcmp(s, "queue") == 0 ? 2 : 1);
+    if (const char* s = getenv("CRUCIBLE_QUEUE_BATCH")) h->queue_min_batch = std::min(64, std::max(1, atoi(s)));
+    if (const char* s = getenv("CRUCIBLE_QUEUE_PATIENCE")) h->queue_patience = std::max(0, atoi(s));
+    if (const char* s = getenv("CRUCIBLE_QUEUE_WALKERS")) h->queue_walk_waves = std::min(15, std::max(1, atoi(s)));
     if (const char* s = getenv("CRUCIBLE_WF_SLOTS")) h->wf_slots = (uint32_t)std::max(64L, atol(s));
     if (const char* s = getenv("CRUCIBLE_WF_SAMPLE_MB")) h->wf_sample_bytes = (size_t)std::max(1L, atol(s)) << 20;
     *out = h;
@@ -818,6 +883,15 @@ int32_t cr_render_host(CrHandle* h, const CrCameraDesc* cam, const CrRenderParam
     return CR_OK;
 }
 
+static int32_t check_queue_abort(CrHandle* h) {
+    if (!h->check_abort) return CR_OK;
+    uint64_t aborted = 0;
+    HIP_TRY(h, hipMemcpy(&aborted, (uint64_t*)h->counters.p + 4, sizeof aborted, hipMemcpyDeviceToHost));
+    h->check_abort = false;
+    if (aborted) return fail(h, CR_ERR_HIP, "queue pipeline: a wave timed out waiting on an LDS queue (image incomplete)");
+    return CR_OK;
+}
+
 int32_t cr_last_kernel_ms(CrHandle* h, double* out_ms) {
     if (!h || !out_ms) return CR_ERR_INVALID_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -825,14 +899,14 @@ int32_t cr_last_kernel_ms(CrHandle* h, double* out_ms) {
     float ms = 0;
     HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *out_ms = ms;
-    return CR_OK;
+    return check_queue_abort(h);
 }
 
 int32_t cr_synchronize(CrHandle* h) {
     if (!h) return CR_ERR_INVALID_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return CR_OK;
+    return check_queue_abort(h);
 }
 
 void* cr_stream(CrHandle* h) { return h ? (void*)h->stream : nullptr; }

@@ -201,6 +201,8 @@ template <typename real> struct KernelArgs {
     real* out;
     uint32_t walk_exit_lanes;   // megakernel: leave the walk once this many lanes are done walking (speed only)
     uint32_t walk_round_steps;  // wrappers a lane may step through before the wave intersects the parked leaves (speed only)
+    uint32_t queue_walk_waves;  // queue_kernel: how many of the workgroup's 16 waves walk (the rest shade)
+    uint32_t queue_min_batch, queue_patience;   // queue_kernel: shaders wait for this many hits, at most this many polls
 };
 
 // ------------------------------------------------------------------ timeline (timeline/mod.rs:233-263)
@@ -514,8 +516,20 @@ CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<re
         real a = real(0.5) * (ud.y + real(1));
         col = c_add(c_scale(real(1) - a, mk<real>(1, 1, 1)), c_scale(a, mk<real>(real(0.5), real(0.7), real(1))));
     }
-    // unwind: a_1 * (a_2 * ( ... (a_n * sky)))
-    for (int32_t k = stack_n - 1; k >= 0; k--) {
+    // unwind: a_1 * (a_2 * ( ... (a_n * sky))).  The factors live in global memory; four levels are fetched
+    // per round trip and applied innermost-first, so the product is formed in the reference's order.
+    int32_t k = stack_n - 1;
+    for (; k >= 3; k -= 4) {
+        V3<real> a[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            size_t at = (size_t)(k - j) * stack_stride + stack_slot;
+            a[j] = mk<real>(A.att_stack[at], A.att_stack[plane + at], A.att_stack[2 * plane + at]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) col = c_mul(a[j], col);
+    }
+    for (; k >= 0; k--) {
         size_t at = (size_t)k * stack_stride + stack_slot;
         V3<real> a_k = mk<real>(A.att_stack[at], A.att_stack[plane + at], A.att_stack[2 * plane + at]);
         col = c_mul(a_k, col);

@@ -80,7 +80,7 @@ def test_book1_against_live_oracle(renderer, oracles, rt, tag):
     img, st = gpu_render(renderer, sc, rt, seed=77)
     ref, rst = oracles[rt].render_image(sc, seed=77)
     assert_exact(img, st, ref, rst)
-    assert st["scene_in_lds"] == 1 and st["bvh_entries"] == rst["bvh_entries"]
+    assert st["scene_in_lds"] in (1, 2) and st["bvh_entries"] == rst["bvh_entries"]
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
@@ -217,12 +217,16 @@ def test_teapot_with_environment_map(renderer, oracles, rt, tag):
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
 @pytest.mark.parametrize("env", [{"CRUCIBLE_PIPELINE": "wavefront"}, {"CRUCIBLE_PIPELINE": "wavefront", "CRUCIBLE_WF_SLOTS": "4096", "CRUCIBLE_WF_SAMPLE_MB": "1"},
-                                 {"CRUCIBLE_WALK_EXIT": "24"}, {"CRUCIBLE_BLOCK": "256"}],
-                         ids=["wavefront", "wavefront-small-batches", "walk-exit-24", "block-256"])
+                                 {"CRUCIBLE_WALK_EXIT": "24"}, {"CRUCIBLE_BLOCK": "256"}, {"CRUCIBLE_PIPELINE": "queue"},
+                                 {"CRUCIBLE_PIPELINE": "queue", "CRUCIBLE_QUEUE_WALKERS": "3", "CRUCIBLE_QUEUE_BATCH": "1"},
+                                 {"CRUCIBLE_PIPELINE": "queue", "CRUCIBLE_QUEUE_WALKERS": "15", "CRUCIBLE_WALK_ROUND": "2"}],
+                         ids=["wavefront", "wavefront-small-batches", "walk-exit-24", "block-256", "queue", "queue-3-walkers",
+                              "queue-15-walkers"])
 def test_alternative_schedules_are_bit_identical(oracles, monkeypatch, rt, tag, env):
     """The wavefront pipeline (logic / extend / finalize kernels over SoA path state, also with tiny slot counts
-    and many sample batches), an early walk exit and another workgroup size only change WHEN a path's operations
-    run, never which: images and counters stay bit-equal to the oracle."""
+    and many sample batches), the LDS-queue megakernel (walker and shader waves exchanging path slots through
+    LDS rings, at several splits), an early walk exit and another workgroup size only change WHEN a path's
+    operations run, never which: images and counters stay bit-equal to the oracle."""
     from crucible_amd.renderer import Renderer
     for k, v in env.items():
         monkeypatch.setenv(k, v)
