@@ -260,6 +260,20 @@ def test_alternative_schedules_are_bit_identical(oracles, monkeypatch, rt, tag, 
         r.close()
 
 
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+def test_earth_demo_scene(renderer, oracles, rt, tag):
+    """demo_images.rs:202-221: a globe with the earthmap.jpg image texture (sphere u,v through acos/atan2, so the
+    libm carve-out applies) under the default sky."""
+    from crucible_amd.demo_builder import earth
+    sc = earth(1, image_width=96, samples=3)
+    assert sc.flatten().images[0].width == 1024 and sc.flatten().images[0].height == 512
+    img, st = gpu_render(renderer, sc, rt)
+    ref, rst = oracles[rt].render_image(sc, seed=SEED)
+    assert st["texel_fetches"] > 0 and abs(int(st["texel_fetches"]) - int(rst["texel_fetches"])) <= 4
+    assert_close(img, ref)
+    assert (img == ref).all(axis=2).mean() > 0.98
+
+
 def test_device_output_and_async_path(renderer):
     import torch
     sc = book1_end_scene(1, scene_seed=1, image_width=72, samples=3)
