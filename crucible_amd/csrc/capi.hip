@@ -10,6 +10,7 @@
 #include "queue.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -47,6 +48,8 @@ template <typename real> struct DevScene {
     int32_t n_entries = 0, n_prims = 0, n_mats = 0, n_texs = 0, n_scene_keys = 0;
     size_t lds_bytes = 0;
     bool animated = false;
+    std::vector<Entry<real>> host_entries;   // what the device walks (for cr_export_bvh)
+    std::vector<int32_t> leaf_desc;          // leaf-order position -> index in the caller's primitive list
     void release() { entries.release(); prims.release(); mats.release(); texs.release(); keys.release(); built = false; }
 };
 
@@ -64,7 +67,7 @@ struct CrHandle {
     std::vector<CrMaterial> materials;
     std::vector<CrTexture> textures;
     std::vector<CrKeyframe> keys;
-    int32_t sky_kind = 0, sky_image = -1;
+    int32_t sky_kind = 0, sky_image = -1, bvh_mode = 0;
     // images are precision independent
     DevBuf images, texels;
     int32_t n_images = 0;
@@ -185,34 +188,175 @@ template <typename real> struct Builder {
         return sizes.at(span);
     }
 
-  public:
-    // DFS pre-order -> level order with explicit links.  In pre-order the left child of inner entry i is
-    // i + 1 and `skip` already names the next wrapper after the subtree; storing the tree level by level
-    // (stable in DFS order within a level) puts the top of the tree first, which is what a partial LDS
-    // copy wants.  The walk order is unchanged: it follows the links, not the storage order.
-    void relayout_bfs() {
-        const int32_t n = (int32_t)entries.size();
-        if (n == 0) return;
-        std::vector<int32_t> level(n, 0), order_idx(n), new_of(n + 1);
-        std::vector<int32_t> stack_end;   // ends (skip) of the enclosing inner wrappers
-        for (int32_t i = 0; i < n; i++) {
-            while (!stack_end.empty() && stack_end.back() <= i) stack_end.pop_back();
-            level[i] = (int32_t)stack_end.size();
-            if (entries[i].leaf < 0) stack_end.push_back(entries[i].skip);
+};
+
+// DFS pre-order -> level order with explicit links.  In pre-order the left child of inner entry i is
+// i + 1 and `skip` already names the next wrapper after the subtree; storing the tree level by level
+// (stable in DFS order within a level) puts the top of the tree first, which is what a partial LDS
+// copy wants.  The walk order is unchanged: it follows the links, not the storage order.
+template <typename real> void relayout_bfs(std::vector<Entry<real>>& entries) {
+    const int32_t n = (int32_t)entries.size();
+    if (n == 0) return;
+    std::vector<int32_t> level(n, 0), order_idx(n), new_of(n + 1);
+    std::vector<int32_t> stack_end;   // ends (skip) of the enclosing inner wrappers
+    for (int32_t i = 0; i < n; i++) {
+        while (!stack_end.empty() && stack_end.back() <= i) stack_end.pop_back();
+        level[i] = (int32_t)stack_end.size();
+        if (entries[i].leaf < 0) stack_end.push_back(entries[i].skip);
+    }
+    for (int32_t i = 0; i < n; i++) order_idx[i] = i;
+    std::stable_sort(order_idx.begin(), order_idx.end(), [&](int32_t a, int32_t b) { return level[a] < level[b]; });
+    for (int32_t k = 0; k < n; k++) new_of[order_idx[k]] = k;
+    new_of[n] = n;
+    std::vector<Entry<real>> out(n);
+    for (int32_t k = 0; k < n; k++) {
+        const int32_t i = order_idx[k];
+        Entry<real> e = entries[i];
+        e.skip = new_of[e.skip];
+        if (e.leaf < 0) e.leaf = -new_of[i + 1];   // left child
+        out[k] = e;
+    }
+    entries.swap(out);
+}
+
+// SURVEY 8(f) row 1 -- CR_BVH_SAH: a binned surface-area-heuristic builder (16 bins per axis on the
+// primitive-box centroids, all three axes tried, cost = area_L * n_L + area_R * n_R) instead of the
+// reference's median split.  It emits the same wrapper array (boxes = union of the range's primitive boxes,
+// leaves of one or two primitives, walked left then right with the shrinking interval), so the kernels and
+// BVHWrapper::hit's semantics are unchanged; only the topology differs.  Decisions are made in f64 from the
+// `real` boxes and are deterministic (stable partition, fixed tie-breaks), so cr_export_bvh reproduces the
+// tree for a checker.
+template <typename real> struct SahBuilder {
+    const std::vector<real>* bmin;   // [3]
+    const std::vector<real>* bmax;   // [3]
+    std::vector<int32_t>* order;
+    struct Node { real b[6]; int32_t left, right, start, end; };
+    std::vector<Node> nodes;
+    std::atomic<int32_t> next{0};
+    static constexpr int kBins = 16;
+
+    static double area(const double lo[3], const double hi[3]) {
+        const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    }
+
+    void build_root(int32_t n) {
+        nodes.assign((size_t)std::max(1, 2 * n), Node());
+        next = 1;
+        build(0, 0, n, 0);
+    }
+
+    void build(int32_t ni, int32_t start, int32_t end, int depth) {
+        std::vector<int32_t>& ord = *order;
+        Node nd;
+        nd.left = nd.right = -1; nd.start = start; nd.end = end;
+        real lo[3], hi[3];
+        double clo[3], chi[3];
+        for (int a = 0; a < 3; a++) { lo[a] = r_inf(real(0)); hi[a] = -r_inf(real(0)); clo[a] = INFINITY; chi[a] = -INFINITY; }
+        for (int32_t i = start; i < end; i++) {
+            const int32_t p = ord[i];
+            for (int a = 0; a < 3; a++) {
+                lo[a] = lo[a] <= bmin[a][p] ? lo[a] : bmin[a][p];
+                hi[a] = hi[a] >= bmax[a][p] ? hi[a] : bmax[a][p];
+                const double cen = 0.5 * ((double)bmin[a][p] + (double)bmax[a][p]);
+                clo[a] = std::min(clo[a], cen); chi[a] = std::max(chi[a], cen);
+            }
         }
-        for (int32_t i = 0; i < n; i++) order_idx[i] = i;
-        std::stable_sort(order_idx.begin(), order_idx.end(), [&](int32_t a, int32_t b) { return level[a] < level[b]; });
-        for (int32_t k = 0; k < n; k++) new_of[order_idx[k]] = k;
-        new_of[n] = n;
-        std::vector<Entry<real>> out(n);
-        for (int32_t k = 0; k < n; k++) {
-            const int32_t i = order_idx[k];
-            Entry<real> e = entries[i];
-            e.skip = new_of[e.skip];
-            if (e.leaf < 0) e.leaf = -new_of[i + 1];   // left child
-            out[k] = e;
+        nd.b[0] = lo[0]; nd.b[1] = hi[0]; nd.b[2] = lo[1]; nd.b[3] = hi[1]; nd.b[4] = lo[2]; nd.b[5] = hi[2];
+        const int32_t span = end - start;
+        if (span <= 2) { nodes[ni] = nd; return; }
+
+        int best_axis = -1, best_plane = -1;
+        double best_cost = INFINITY;
+        for (int a = 0; a < 3; a++) {
+            const double ext = chi[a] - clo[a];
+            if (!(ext > 0.0) || !std::isfinite(ext)) continue;
+            const double scale = (double)kBins / ext;
+            int32_t cnt[kBins] = {0};
+            double blo[kBins][3], bhi[kBins][3];
+            for (int k = 0; k < kBins; k++) for (int d = 0; d < 3; d++) { blo[k][d] = INFINITY; bhi[k][d] = -INFINITY; }
+            for (int32_t i = start; i < end; i++) {
+                const int32_t p = ord[i];
+                const double cen = 0.5 * ((double)bmin[a][p] + (double)bmax[a][p]);
+                int k = (int)((cen - clo[a]) * scale);
+                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                cnt[k]++;
+                for (int d = 0; d < 3; d++) { blo[k][d] = std::min(blo[k][d], (double)bmin[d][p]); bhi[k][d] = std::max(bhi[k][d], (double)bmax[d][p]); }
+            }
+            double r_area[kBins];
+            int32_t r_cnt[kBins];
+            {   // suffix sweep: everything in bins k..end
+                double l3[3] = {INFINITY, INFINITY, INFINITY}, h3[3] = {-INFINITY, -INFINITY, -INFINITY};
+                int32_t c = 0;
+                for (int k = kBins - 1; k >= 1; k--) {
+                    if (cnt[k]) for (int d = 0; d < 3; d++) { l3[d] = std::min(l3[d], blo[k][d]); h3[d] = std::max(h3[d], bhi[k][d]); }
+                    c += cnt[k];
+                    r_cnt[k] = c; r_area[k] = c ? area(l3, h3) : 0.0;
+                }
+            }
+            double l3[3] = {INFINITY, INFINITY, INFINITY}, h3[3] = {-INFINITY, -INFINITY, -INFINITY};
+            int32_t c = 0;
+            for (int k = 0; k + 1 < kBins; k++) {   // plane k: bins 0..k | k+1..end
+                if (cnt[k]) for (int d = 0; d < 3; d++) { l3[d] = std::min(l3[d], blo[k][d]); h3[d] = std::max(h3[d], bhi[k][d]); }
+                c += cnt[k];
+                if (c == 0 || r_cnt[k + 1] == 0) continue;
+                const double cost = area(l3, h3) * (double)c + r_area[k + 1] * (double)r_cnt[k + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_plane = k; }
+            }
         }
-        entries.swap(out);
+        int32_t mid;
+        if (best_axis < 0) mid = start + span / 2;   // coincident centroids (or non-finite extents): split the list
+        else {
+            const int a = best_axis;
+            const double scale = (double)kBins / (chi[a] - clo[a]);
+            auto it = std::stable_partition(ord.begin() + start, ord.begin() + end, [&](int32_t p) {
+                const double cen = 0.5 * ((double)bmin[a][p] + (double)bmax[a][p]);
+                int k = (int)((cen - clo[a]) * scale);
+                k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                return k <= best_plane;
+            });
+            mid = (int32_t)(it - ord.begin());
+        }
+        nd.left = next.fetch_add(2);
+        nd.right = nd.left + 1;
+        nodes[ni] = nd;
+        if (depth < 4 && span >= (1 << 15)) {   // the halves touch disjoint ranges of `order` and distinct nodes
+            std::thread t([&] { build(nd.left, start, mid, depth + 1); });
+            build(nd.right, mid, end, depth + 1);
+            t.join();
+        } else {
+            build(nd.left, start, mid, depth + 1);
+            build(nd.right, mid, end, depth + 1);
+        }
+    }
+
+    // Node graph -> pre-order wrapper array with skip links (the layout Builder emits).
+    void linearise(std::vector<Entry<real>>& out) const {
+        out.clear();
+        std::vector<int32_t> stack{0}, open;   // open: pre-order indices of inner wrappers awaiting their end
+        std::vector<std::pair<int32_t, int32_t>> todo;   // (node, pre-order index of the parent) -- iterative DFS
+        struct Frame { int32_t node; int32_t state; int32_t idx; };
+        std::vector<Frame> fr{{0, 0, -1}};
+        while (!fr.empty()) {
+            Frame& f = fr.back();
+            const Node& nd = nodes[f.node];
+            if (f.state == 0) {
+                f.idx = (int32_t)out.size();
+                Entry<real> e;
+                for (int k = 0; k < 6; k++) e.b[k] = nd.b[k];
+                e.skip = f.idx + 1; e.leaf = -1;
+                if (nd.left < 0) { e.leaf = (nd.start << 1) | (nd.end - nd.start - 1); out.push_back(e); fr.pop_back(); continue; }
+                out.push_back(e);
+                f.state = 1;
+                fr.push_back({nd.left, 0, -1});
+            } else if (f.state == 1) {
+                f.state = 2;
+                fr.push_back({nd.right, 0, -1});
+            } else {
+                out[f.idx].skip = (int32_t)out.size();
+                fr.pop_back();
+            }
+        }
     }
 };
 
@@ -251,7 +395,13 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
             }
         }
     }
-    if (n > 0) { b.build_root(n); b.relayout_bfs(); }
+    if (n > 0 && h->bvh_mode == CR_BVH_SAH) {
+        SahBuilder<real> sb;
+        sb.bmin = b.bmin; sb.bmax = b.bmax; sb.order = &b.order;
+        sb.build_root(n);
+        sb.linearise(b.entries);
+        relayout_bfs(b.entries);
+    } else if (n > 0) { b.build_root(n); relayout_bfs(b.entries); }
     std::vector<Prim<real>> leaf_prims(n);
     for (int32_t i = 0; i < n; i++) leaf_prims[i] = src[b.order[i]];
 
@@ -325,6 +475,9 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
     ds.lds_bytes = r16(b.entries.size() * sizeof(Entry<real>)) + r16(leaf_prims.size() * sizeof(Prim<real>)) +
                    r16(mats.size() * sizeof(Mat<real>)) + r16(texs.size() * sizeof(Tex<real>));
     ds.animated = any_keys;
+    ds.host_entries = b.entries;
+    ds.leaf_desc.resize(n);
+    for (int32_t i = 0; i < n; i++) ds.leaf_desc[i] = vis[b.order[i]];
     ds.built = true;
     h->upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return CR_OK;
@@ -704,6 +857,49 @@ uint32_t display_byte(double c) {   // impl Display for Color, utils.rs:422-437:
 
 }   // namespace
 
+// cr_export_bvh: the wrapper tree the device walks, re-expressed as the reference's BVHWrapper tree (each
+// wrapper = box + left/right child) in walk order.  A leaf wrapper of one primitive holds it twice, as the
+// reference's span-1 wrappers do (bvhwrapper.rs:58-60).
+template <typename real>
+int32_t export_bvh(CrHandle* h, double* boxes, int32_t* children, int32_t capacity, int32_t* n_out) {
+    int32_t rc = build_dev_scene<real>(h);
+    if (rc != CR_OK) return rc;
+    const DevScene<real>& ds = dev_scene<real>(h);
+    const std::vector<Entry<real>>& E = ds.host_entries;
+    *n_out = (int32_t)E.size();
+    if (!boxes || !children || capacity < (int32_t)E.size()) return E.empty() || (!boxes && !children) ? CR_OK : fail(h, CR_ERR_INVALID_ARG, "cr_export_bvh: capacity too small");
+    if (E.empty()) return CR_OK;
+    struct Frame { int32_t entry, out, state; };
+    std::vector<Frame> fr{{0, -1, 0}};
+    int32_t n = 0;
+    while (!fr.empty()) {
+        Frame& f = fr.back();
+        const Entry<real>& e = E[f.entry];
+        if (f.state == 0) {
+            f.out = n++;
+            for (int k = 0; k < 6; k++) boxes[6 * f.out + k] = (double)e.b[k];
+            if (e.leaf >= 0) {
+                const int32_t first = e.leaf >> 1, count = (e.leaf & 1) + 1;
+                children[2 * f.out] = ~ds.leaf_desc[first];
+                children[2 * f.out + 1] = ~ds.leaf_desc[first + count - 1];
+                fr.pop_back();
+                continue;
+            }
+            f.state = 1;
+            children[2 * f.out] = n;                 // the left child is exported next
+            const int32_t left = -e.leaf;
+            fr.push_back({left, -1, 0});
+        } else if (f.state == 1) {
+            f.state = 2;
+            children[2 * f.out + 1] = n;
+            const int32_t right = E[-e.leaf].skip;   // the wrapper after the left subtree
+            fr.push_back({right, -1, 0});
+        } else fr.pop_back();
+    }
+    return CR_OK;
+}
+
+
 extern "C" {
 
 int32_t cr_abi_version(void) { return CR_ABI_VERSION; }
@@ -806,6 +1002,7 @@ int32_t cr_upload_scene(CrHandle* h, const CrSceneDesc* s) {
         if (p.kind == CR_PRIM_SPHERE && !(p.v[3] >= 0.0)) return fail(h, CR_ERR_INVALID_ARG, "Cannot make a sphere with negative radius");   // sphere.rs:26
     }
     if (s->sky_kind != CR_SKY_DEFAULT && s->sky_kind != CR_SKY_SPHERICAL) return fail(h, CR_ERR_INVALID_ARG, "unknown sky kind");
+    if (s->bvh_mode != CR_BVH_REFERENCE && s->bvh_mode != CR_BVH_SAH) return fail(h, CR_ERR_INVALID_ARG, "unknown bvh_mode");
     if (s->sky_kind == CR_SKY_SPHERICAL && (s->sky_image < 0 || s->sky_image >= s->n_images)) return fail(h, CR_ERR_INVALID_ARG, "sky image index out of range");
     for (int i = 0; i < s->n_images; i++)
         if (s->images[i].width < 1 || s->images[i].height < 1 || !s->images[i].rgb8) return fail(h, CR_ERR_INVALID_ARG, "bad image");
@@ -817,7 +1014,7 @@ int32_t cr_upload_scene(CrHandle* h, const CrSceneDesc* s) {
     h->materials.assign(s->materials, s->materials + s->n_materials);
     h->textures.assign(s->textures, s->textures + s->n_textures);
     h->keys.assign(s->keys, s->keys + s->n_keys);
-    h->sky_kind = s->sky_kind; h->sky_image = s->sky_image;
+    h->sky_kind = s->sky_kind; h->sky_image = s->sky_image; h->bvh_mode = s->bvh_mode;
     h->s32.built = false; h->s64.built = false;
     // images: RGB8 -> RGBA8 words, one flat texel array
     std::vector<ImageRef> refs(s->n_images);
@@ -890,6 +1087,16 @@ static int32_t check_queue_abort(CrHandle* h) {
     h->check_abort = false;
     if (aborted) return fail(h, CR_ERR_HIP, "queue pipeline: a wave timed out waiting on an LDS queue (image incomplete)");
     return CR_OK;
+}
+
+int32_t cr_export_bvh(CrHandle* h, int32_t real_type, double* boxes, int32_t* children, int32_t capacity, int32_t* n_wrappers) {
+    if (!h) return CR_ERR_INVALID_ARG;
+    if (!n_wrappers) return fail(h, CR_ERR_INVALID_ARG, "cr_export_bvh: null n_wrappers");
+    if (!h->has_scene) return fail(h, CR_ERR_NO_SCENE, "cr_export_bvh before cr_upload_scene");
+    if (real_type != CR_REAL_F32 && real_type != CR_REAL_F64) return fail(h, CR_ERR_INVALID_ARG, "unknown real_type");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return real_type == CR_REAL_F64 ? export_bvh<double>(h, boxes, children, capacity, n_wrappers)
+                                    : export_bvh<float>(h, boxes, children, capacity, n_wrappers);
 }
 
 int32_t cr_last_kernel_ms(CrHandle* h, double* out_ms) {

@@ -184,6 +184,7 @@ class _PrebuiltScene(Scene):
     """A Scene whose flat description was generated directly (a million Python Sphere objects buy nothing)."""
 
     def flatten(self):
+        self._flat.desc.bvh_mode = self.bvh_mode
         return self._flat
 
 

@@ -290,6 +290,7 @@ public:
     size_t frame_rate;
     uint64_t seed = 0xC0FFEE;
     int real_type = CR_REAL_F32;
+    int bvh_mode = CR_BVH_REFERENCE;   // CR_BVH_SAH: the quality builder (include/crucible_hip.h)
     int device = 0;
 
     Scene(double aspect, uint32_t width, size_t rate, double shutter, size_t threads)
@@ -372,6 +373,7 @@ public:
         int sky_kind = CR_SKY_DEFAULT, sky_image = -1;
         if (skybox) { sky_kind = CR_SKY_SPHERICAL; sky_image = image_id(skybox); }
         f.finish(sky_kind, sky_image);
+        f.desc.bvh_mode = bvh_mode;
         return f;
     }
 

@@ -289,6 +289,7 @@ class Scene:
         self.seed = 0xC0FFEE
         self.real_type = A.CR_REAL_F32
         self.device = 0
+        self.bvh_mode = A.CR_BVH_REFERENCE   # A.CR_BVH_SAH: the quality builder (include/crucible_hip.h)
 
     @classmethod
     def new_image(cls, aspect_ratio, image_width, frame_rate, shutter_angle, thread_count):
@@ -414,7 +415,9 @@ class Scene:
         sky_kind, sky_image = A.CR_SKY_DEFAULT, -1
         if self.skybox is not None:
             sky_kind, sky_image = A.CR_SKY_SPHERICAL, image_id(self.skybox)
-        return FlatScene(prims, materials, textures, images, keys, sky_kind, sky_image)
+        flat = FlatScene(prims, materials, textures, images, keys, sky_kind, sky_image)
+        flat.desc.bvh_mode = self.bvh_mode
+        return flat
 
     # ---- Camera::render over the HIP library (scene/mod.rs:283-347)
     def compute_frame_count(self):

@@ -138,6 +138,20 @@ typedef struct CrKeyframe {
     double a, b;
 } CrKeyframe;
 
+/*
+ * Which wrapper tree cr_upload_scene builds over the visible primitives.
+ *   CR_BVH_REFERENCE  BVHWrapper::help_generate's median split (src/objects/bvhwrapper.rs:46-78):
+ *                     the tree the reference walks, hence the parity mode and the default.
+ *   CR_BVH_SAH        SURVEY 8(f) row 1: binned surface-area-heuristic topology.  Same wrapper kind
+ *                     (box = union of the primitive boxes, leaves of 1-2 primitives), same walk
+ *                     (BVHWrapper::hit, bvhwrapper.rs:96-126: left then right, shrinking interval),
+ *                     fewer box tests.  The closest hit equals the reference tree's except where a
+ *                     ray grazes a box face (Aabb::hit's `max <= min` miss, bvh.rs:96-132), so
+ *                     images are not guaranteed bit-identical to CR_BVH_REFERENCE; cr_export_bvh
+ *                     hands a checker the exact tree.
+ */
+enum { CR_BVH_REFERENCE = 0, CR_BVH_SAH = 1 };
+
 typedef struct CrSceneDesc {
     int32_t n_prims;
     int32_t n_materials;
@@ -146,7 +160,7 @@ typedef struct CrSceneDesc {
     int32_t n_keys;
     int32_t sky_kind;
     int32_t sky_image;
-    int32_t _pad;
+    int32_t bvh_mode;       /* CR_BVH_REFERENCE (0) | CR_BVH_SAH */
     const CrPrimitive* prims;
     const CrMaterial* materials;
     const CrTexture* textures;
@@ -248,6 +262,15 @@ CR_API int32_t cr_render_device(CrHandle* h, const CrCameraDesc* cam, const CrRe
 /* Same, into a HOST buffer (render + device->host copy, synchronous). */
 CR_API int32_t cr_render_host(CrHandle* h, const CrCameraDesc* cam, const CrRenderParams* params,
                        void* h_out_rgb, CrStats* stats);
+
+/* The wrapper tree the device walks for `real_type`, as BVHWrapper's shape (src/objects/bvhwrapper.rs:7-11):
+ * wrapper k has boxes[6k..6k+5] = xmin,xmax,ymin,ymax,zmin,zmax (exact values of `real_type`) and
+ * children[2k], children[2k+1] = left, right: >= 0 another wrapper's index, < 0 the bitwise complement of a
+ * primitive's index in CrSceneDesc.prims.  Wrappers are numbered in walk order (root 0, left subtree, right
+ * subtree); a one-primitive wrapper names that primitive twice (bvhwrapper.rs:58-60).  *n_wrappers receives the
+ * count; boxes/children may be NULL to query it.  Builds the tree if the scene was not rendered yet. */
+CR_API int32_t cr_export_bvh(CrHandle* h, int32_t real_type, double* boxes, int32_t* children, int32_t capacity,
+                             int32_t* n_wrappers);
 
 /* Wait for the last render launched on this handle and return its kernel time in
  * milliseconds, measured with HIP events recorded on the handle's stream around the

@@ -1059,6 +1059,34 @@ static int dump_rec(const Scene* sc, const Hittable* h, real* boxes, int32_t* ki
     if (h->right != h->left) n = dump_rec(sc, h->right, boxes, kids, cap, n);
     return n;
 }
+/* Replace the scene's wrapper tree by a given one (the shape cr_export_bvh writes: per wrapper 6 doubles
+ * xmin,xmax,ymin,ymax,zmin,zmax and (left,right): >= 0 wrapper index, < 0 ~index of a primitive in the
+ * desc list; wrapper 0 is the root).  The walk stays BVHWrapper::hit (bvhwrapper.rs:96-126); only the
+ * topology and boxes are the caller's.  Used to check the library's CR_BVH_SAH mode: the reference builds
+ * no such tree, so that mode is pinned only by this walk.  Returns 0, or -1 on a malformed tree. */
+EXPORT int32_t oracle_set_tree(Scene* sc, const double* boxes, const int32_t* kids, int32_t n) {
+    if (n <= 0) return -1;
+    for (int i = 0; i < 2 * n; i++) {
+        if (kids[i] >= n || (kids[i] >= 0 && kids[i] <= i / 2)) return -1;   /* children come after their parent */
+        if (kids[i] < 0 && ~kids[i] >= sc->n_prims) return -1;
+    }
+    Hittable* pool = (Hittable*)calloc((size_t)n, sizeof(Hittable));
+    for (int i = 0; i < n; i++) {
+        Hittable* w = &pool[i];
+        const double* b = boxes + 6 * i;
+        w->kind = H_BVH;
+        w->bbox.x.min = (real)b[0]; w->bbox.x.max = (real)b[1];
+        w->bbox.y.min = (real)b[2]; w->bbox.y.max = (real)b[3];
+        w->bbox.z.min = (real)b[4]; w->bbox.z.max = (real)b[5];
+        w->left = kids[2 * i] >= 0 ? &pool[kids[2 * i]] : &sc->prims[~kids[2 * i]];
+        w->right = kids[2 * i + 1] >= 0 ? &pool[kids[2 * i + 1]] : &sc->prims[~kids[2 * i + 1]];
+    }
+    free(sc->pool);
+    sc->pool = pool; sc->pool_used = n; sc->pool_cap = n;
+    sc->world = &pool[0];
+    return 0;
+}
+
 EXPORT int32_t oracle_bvh_dump(const Scene* sc, real* boxes, int32_t* kids, int32_t cap) {
     return dump_rec(sc, sc->world, boxes, kids, cap, 0);
 }

@@ -74,6 +74,8 @@ class Oracle:
         L.oracle_rng_uniforms.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, P]
         L.oracle_rng_u64.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, P]
         L.oracle_bvh_dump.argtypes = [P, P, P, C.c_int32]
+        L.oracle_set_tree.argtypes = [P, P, P, C.c_int32]
+        L.oracle_set_tree.restype = C.c_int32
 
     # ---- helpers
     def arr(self, x):
@@ -97,6 +99,13 @@ class Oracle:
     def scene_destroy(self, h):
         self.lib.oracle_scene_destroy(h)
 
+    def set_tree(self, scene_h, boxes, kids):
+        """Walk this wrapper tree (cr_export_bvh's output) instead of the reference-built one."""
+        boxes = np.ascontiguousarray(boxes, dtype=np.float64)
+        kids = np.ascontiguousarray(kids, dtype=np.int32)
+        rc = self.lib.oracle_set_tree(scene_h, boxes.ctypes.data, kids.ctypes.data, len(kids))
+        assert rc == 0, "malformed wrapper tree"
+
     def render(self, scene_h, cam, *, seed, sample_begin=0, sample_count=None, output_sum=False, pix_begin=0,
                pix_end=None, n_threads=None):
         """Returns (H*W*3 array reshaped (n_pix,3) of reals, stats dict)."""
@@ -113,10 +122,12 @@ class Oracle:
         assert rc == 0, rc
         return out, st.as_dict()
 
-    def render_image(self, scene, *, seed, n_threads=None, **kw):
+    def render_image(self, scene, *, seed, n_threads=None, tree=None, **kw):
         flat = scene.flatten()
         h = self.scene_create(flat)
         try:
+            if tree is not None:
+                self.set_tree(h, *tree)
             out, st = self.render(h, scene.scene_cam, seed=seed, n_threads=n_threads, **kw)
         finally:
             self.scene_destroy(h)

@@ -55,11 +55,14 @@ def test_cli_errors_like_the_reference(cli):
 
 
 @pytest.mark.gpu
-def test_cli_renders_the_same_ppm_as_python(cli, renderer, tmp_path):
+@pytest.mark.parametrize("bvh,mode", [("reference", A.CR_BVH_REFERENCE), ("sah", A.CR_BVH_SAH)])
+def test_cli_renders_the_same_ppm_as_python(cli, renderer, tmp_path, bvh, mode):
     stem = str(tmp_path / "cli")
-    subprocess.check_call([cli, "--file", stem, "--world", "1", "--width", "64", "--samples", "3", "--real", "f64"], cwd=ROOT)
+    subprocess.check_call([cli, "--file", stem, "--world", "1", "--width", "64", "--samples", "3", "--real", "f64",
+                           "--bvh", bvh], cwd=ROOT)
     sc = book1_end_scene(1, scene_seed=1, image_width=64, samples=3)
     sc.real_type = A.CR_REAL_F64
+    sc.bvh_mode = mode
     sc.render_image(str(tmp_path / "py"), renderer=renderer)
     assert open(stem + ".ppm").read() == open(str(tmp_path / "py") + ".ppm").read()
 
