@@ -56,7 +56,7 @@ class CrRenderParams(C.Structure):
     _fields_ = [("samples", C.c_int32), ("sample_begin", C.c_int32), ("sample_count", C.c_int32),
                 ("max_depth", C.c_int32), ("seed", C.c_uint64), ("frame", C.c_int32), ("real_type", C.c_int32),
                 ("frame_rate", C.c_double), ("shutter_angle", C.c_double), ("output_sum", C.c_int32),
-                ("_pad", C.c_int32)]
+                ("refit_boxes", C.c_int32)]
 
 
 class CrStats(C.Structure):

@@ -8,6 +8,7 @@
 #include "pathtrace.hpp"
 #include "wavefront.hpp"
 #include "queue.hpp"
+#include "refit.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -48,9 +49,11 @@ template <typename real> struct DevScene {
     int32_t n_entries = 0, n_prims = 0, n_mats = 0, n_texs = 0, n_scene_keys = 0;
     size_t lds_bytes = 0;
     bool animated = false;
+    DevBuf entries_refit;                    // working copy whose boxes refit_level_kernel rewrites per frame
+    std::vector<int32_t> level_begin;        // entries of tree level l are [level_begin[l], level_begin[l+1])
     std::vector<Entry<real>> host_entries;   // what the device walks (for cr_export_bvh)
     std::vector<int32_t> leaf_desc;          // leaf-order position -> index in the caller's primitive list
-    void release() { entries.release(); prims.release(); mats.release(); texs.release(); keys.release(); built = false; }
+    void release() { entries.release(); entries_refit.release(); prims.release(); mats.release(); texs.release(); keys.release(); built = false; }
 };
 
 }   // namespace
@@ -194,8 +197,9 @@ template <typename real> struct Builder {
 // i + 1 and `skip` already names the next wrapper after the subtree; storing the tree level by level
 // (stable in DFS order within a level) puts the top of the tree first, which is what a partial LDS
 // copy wants.  The walk order is unchanged: it follows the links, not the storage order.
-template <typename real> void relayout_bfs(std::vector<Entry<real>>& entries) {
+template <typename real> void relayout_bfs(std::vector<Entry<real>>& entries, std::vector<int32_t>& level_begin) {
     const int32_t n = (int32_t)entries.size();
+    level_begin.assign(1, 0);
     if (n == 0) return;
     std::vector<int32_t> level(n, 0), order_idx(n), new_of(n + 1);
     std::vector<int32_t> stack_end;   // ends (skip) of the enclosing inner wrappers
@@ -208,6 +212,8 @@ template <typename real> void relayout_bfs(std::vector<Entry<real>>& entries) {
     std::stable_sort(order_idx.begin(), order_idx.end(), [&](int32_t a, int32_t b) { return level[a] < level[b]; });
     for (int32_t k = 0; k < n; k++) new_of[order_idx[k]] = k;
     new_of[n] = n;
+    for (int32_t k = 1; k < n; k++) if (level[order_idx[k]] != level[order_idx[k - 1]]) level_begin.push_back(k);
+    level_begin.push_back(n);
     std::vector<Entry<real>> out(n);
     for (int32_t k = 0; k < n; k++) {
         const int32_t i = order_idx[k];
@@ -400,8 +406,9 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
         sb.bmin = b.bmin; sb.bmax = b.bmax; sb.order = &b.order;
         sb.build_root(n);
         sb.linearise(b.entries);
-        relayout_bfs(b.entries);
-    } else if (n > 0) { b.build_root(n); relayout_bfs(b.entries); }
+        relayout_bfs(b.entries, ds.level_begin);
+    } else if (n > 0) { b.build_root(n); relayout_bfs(b.entries, ds.level_begin); }
+    else ds.level_begin.assign(1, 0);
     std::vector<Prim<real>> leaf_prims(n);
     for (int32_t i = 0; i < n; i++) leaf_prims[i] = src[b.order[i]];
 
@@ -745,6 +752,7 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     KernelArgs<real> a;
     memset(&a, 0, sizeof a);
     a.entries = (const Entry<real>*)ds.entries.p; a.prims = (const Prim<real>*)ds.prims.p;
+    const bool refit = p->refit_boxes && ds.animated && ds.n_entries > 0;   // without primitive keys the boxes would not change
     a.mats = (const Mat<real>*)ds.mats.p; a.texs = (const Tex<real>*)ds.texs.p;
     a.images = (const ImageRef*)h->images.p; a.texels = (const uint32_t*)h->texels.p;
     a.keys = (const Key<real>*)ds.keys.p;
@@ -793,6 +801,20 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     a.current_time = (real)p->frame * (real(1) / (real)p->frame_rate);                       // ray_casting.rs:77
     a.shutter_length = ((real)p->shutter_angle / real(360)) * (real(1) / (real)p->frame_rate);   // :79
     a.output_sum = p->output_sum;
+    if (refit) {   // refit.hpp: wrapper boxes for this frame's ray times [current_time, current_time + shutter_length]
+        const size_t bytes = (size_t)ds.n_entries * sizeof(Entry<real>);
+        HIP_TRY(h, ds.entries_refit.ensure(bytes));
+        HIP_TRY(h, hipMemcpyAsync(ds.entries_refit.p, ds.entries.p, bytes, hipMemcpyDeviceToDevice, h->stream));
+        for (size_t l = ds.level_begin.size() - 1; l-- > 0;) {
+            const int32_t begin = ds.level_begin[l], end = ds.level_begin[l + 1];
+            if (end <= begin) continue;
+            hipLaunchKernelGGL((refit_level_kernel<real>), dim3((unsigned)((end - begin + 255) / 256)), dim3(256), 0, h->stream,
+                               (Entry<real>*)ds.entries_refit.p, begin, end, (const Prim<real>*)ds.prims.p, (const Key<real>*)ds.keys.p,
+                               a.current_time, a.current_time + a.shutter_length);
+        }
+        HIP_TRY(h, hipGetLastError());
+        a.entries = (const Entry<real>*)ds.entries_refit.p;
+    }
     a.tiles_x = (uint32_t)(c.W + 7) / 8u; a.tiles_y = (uint32_t)(c.H + 7) / 8u;
     a.work_counter = (uint32_t*)h->work_counter.p;
     a.counters = (uint64_t*)h->counters.p;

@@ -47,6 +47,8 @@ CR_HD double r_inf(double) { return __builtin_huge_val(); }
 // f64::min: the non-NaN operand when one is NaN (== fmin)
 CR_HD float r_fmin(float a, float b) { return __builtin_fminf(a, b); }
 CR_HD double r_fmin(double a, double b) { return __builtin_fmin(a, b); }
+CR_HD float r_fmax(float a, float b) { return __builtin_fmaxf(a, b); }
+CR_HD double r_fmax(double a, double b) { return __builtin_fmax(a, b); }
 
 // ------------------------------------------------------------------ Vec3 (utils.rs:72-340)
 template <typename real> struct V3 { real x, y, z; };

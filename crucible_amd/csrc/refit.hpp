@@ -1,0 +1,122 @@
+// BVH refit for keyframed primitives -- SURVEY 8(f) rows 1-2, opt-in through CrRenderParams.refit_boxes.
+//
+// The reference computes a wrapper's box once, from the primitives' construction-time boxes
+// (src/objects/bvhwrapper.rs:47-50), and never again: Hittables::update_bb reaches only leaf primitives and its
+// result is not read (objects/mod.rs:141, bvhwrapper.rs:102-106 carry the author's TODO).  A primitive that a
+// keyframe moves out of its construction-time box is therefore clipped.  With refit_boxes = 0 this library keeps
+// those stale boxes (that is the reference's image); with refit_boxes = 1 every wrapper box is re-derived for the
+// frame before the render, from the same primitives and the same timeline arithmetic:
+//
+//   box of a primitive over the frame's ray-time interval [ta, tb] = union of its box at ta, at tb, at every key
+//   end t1 inside (ta, tb), and at every key start t0 inside (ta, tb] taken twice -- with the key active (the
+//   value from t0 on) and with keys starting exactly at t0 still inactive (the value just before t0).  A keyed
+//   channel is piecewise linear in t with jumps only at key starts (timeline/mod.rs:233-263), so these times
+//   carry its extremes.  The box at one time is Sphere::new's / Triangle::new's (sphere.rs:29-30,
+//   triangle.rs:28-35) on the evaluated position; wrapper box = tight_enclose of its children (bvh.rs:67-73).
+//
+// On a scene without primitive keys this reproduces the construction-time boxes exactly.  The topology is never
+// changed.  (The test suite's CPU checker applies the same rule to its own tree.)
+#pragma once
+#include "pathtrace.hpp"
+
+namespace cr {
+
+// combine_and_compute (timeline/mod.rs:233-263) with a switch for the left limit at a key start:
+// before_start = true treats a key whose t0 equals t as not yet active.
+template <typename real>
+CR_HD void timeline_eval_side(const Key<real>* keys, int n, real t, bool before_start, real& x, real& y, real& z, real& w) {
+    x = real(0) + x; y = real(0) + y; z = real(0) + z;
+    for (int i = 0; i < n; i++) {
+        Key<real> k = keys[i];
+        bool started = before_start ? (k.t0 < t) : (k.t0 <= t);
+        bool active = (t > k.t1) || (started && t <= k.t1);
+        if (!active) continue;
+        real s = clamp01((t - k.t0) / (k.t1 - k.t0));
+        if (k.channel <= 2) {
+            real val = k.interp ? k.a * s : k.a;
+            if (k.channel == 0) x = x + val; else if (k.channel == 1) y = y + val; else z = z + val;
+        } else if (k.channel == 3) {
+            w = k.interp ? k.a + (k.b - k.a) * s : k.a;
+        }
+    }
+}
+
+template <typename real> CR_HD void enclose(real lo[3], real hi[3], const real blo[3], const real bhi[3]) {
+    for (int a = 0; a < 3; a++) {   // Interval::tight_enclose, utils.rs:629-633
+        lo[a] = lo[a] <= blo[a] ? lo[a] : blo[a];
+        hi[a] = hi[a] >= bhi[a] ? hi[a] : bhi[a];
+    }
+}
+
+// Box of primitive p at time t, united into lo/hi.
+template <typename real>
+CR_HD void prim_box_at(const Prim<real>& p, const Key<real>* keys, real t, bool before_start, real lo[3], real hi[3]) {
+    real blo[3], bhi[3];
+    const Key<real>* k = keys + p.key_first;
+    if (p.kind() == 0) {   // Sphere::new, sphere.rs:29-30; Aabb::new_from_points, bvh.rs:44-64
+        real c[3] = {p.g[0], p.g[1], p.g[2]}, r = p.g[3];
+        timeline_eval_side(k, p.key_count, t, before_start, c[0], c[1], c[2], r);
+        for (int a = 0; a < 3; a++) {
+            real l = c[a] + (-r), h = c[a] + r;
+            if (l <= h) { blo[a] = l; bhi[a] = h; } else { blo[a] = h; bhi[a] = l; }
+        }
+    } else {               // Triangle::new, triangle.rs:28-35 (f64::min / f64::max)
+        real v[3][3];
+        for (int j = 0; j < 3; j++) {
+            real w = real(1);
+            v[j][0] = p.g[3 * j]; v[j][1] = p.g[3 * j + 1]; v[j][2] = p.g[3 * j + 2];
+            timeline_eval_side(k, p.key_count, t, before_start, v[j][0], v[j][1], v[j][2], w);
+            v[j][0] = w * v[j][0]; v[j][1] = w * v[j][1]; v[j][2] = w * v[j][2];
+        }
+        for (int a = 0; a < 3; a++) {
+            bhi[a] = r_fmax(v[0][a], r_fmax(v[1][a], v[2][a]));
+            blo[a] = r_fmin(v[0][a], r_fmin(v[1][a], v[2][a]));
+        }
+    }
+    enclose(lo, hi, blo, bhi);
+}
+
+// Box of primitive p over ray times [ta, tb], united into lo/hi (rule in the header comment).
+template <typename real>
+CR_HD void prim_box_over(const Prim<real>& p, const Key<real>* keys, real ta, real tb, real lo[3], real hi[3]) {
+    prim_box_at(p, keys, ta, false, lo, hi);
+    if (p.key_count == 0) return;
+    prim_box_at(p, keys, tb, false, lo, hi);
+    for (int i = 0; i < p.key_count; i++) {
+        const Key<real> k = keys[p.key_first + i];
+        if (ta < k.t0 && k.t0 <= tb) {
+            prim_box_at(p, keys, k.t0, false, lo, hi);
+            prim_box_at(p, keys, k.t0, true, lo, hi);
+        }
+        if (ta < k.t1 && k.t1 < tb) prim_box_at(p, keys, k.t1, false, lo, hi);
+    }
+}
+
+#if defined(__HIPCC__)
+// One level of the tree, deepest level first (entries are stored level by level, children after parents):
+// leaves take their primitives' boxes, inner wrappers the union of their two children, already refitted.
+template <typename real>
+__global__ void refit_level_kernel(Entry<real>* entries, int32_t begin, int32_t end, const Prim<real>* prims,
+                                   const Key<real>* keys, real ta, real tb) {
+    const int32_t i = begin + (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= end) return;
+    const int32_t leaf = entries[i].leaf;
+    real lo[3], hi[3];
+    for (int a = 0; a < 3; a++) { lo[a] = r_inf(real(0)); hi[a] = -r_inf(real(0)); }
+    if (leaf >= 0) {
+        const int32_t first = leaf >> 1, count = (leaf & 1) + 1;
+        for (int32_t k = 0; k < count; k++) prim_box_over(prims[first + k], keys, ta, tb, lo, hi);
+    } else {
+        const Entry<real> l = entries[-leaf];
+        const Entry<real> r = entries[l.skip];   // the wrapper after the left subtree = the right child
+        const real llo[3] = {l.b[0], l.b[2], l.b[4]}, lhi[3] = {l.b[1], l.b[3], l.b[5]};
+        const real rlo[3] = {r.b[0], r.b[2], r.b[4]}, rhi[3] = {r.b[1], r.b[3], r.b[5]};
+        enclose(lo, hi, llo, lhi);
+        enclose(lo, hi, rlo, rhi);
+    }
+    real* b = entries[i].b;
+    b[0] = lo[0]; b[1] = hi[0]; b[2] = lo[1]; b[3] = hi[1]; b[4] = lo[2]; b[5] = hi[2];
+}
+#endif
+
+}   // namespace cr

@@ -291,6 +291,7 @@ public:
     uint64_t seed = 0xC0FFEE;
     int real_type = CR_REAL_F32;
     int bvh_mode = CR_BVH_REFERENCE;   // CR_BVH_SAH: the quality builder (include/crucible_hip.h)
+    bool refit_boxes = false;          // CrRenderParams.refit_boxes: wrapper boxes follow keyframed primitives
     int device = 0;
 
     Scene(double aspect, uint32_t width, size_t rate, double shutter, size_t threads)
@@ -388,7 +389,7 @@ public:
                         {c.look_at_tl.start_pos.x, c.look_at_tl.start_pos.y, c.look_at_tl.start_pos.z},
                         {c.vup.x, c.vup.y, c.vup.z}, (int32_t)fk.size(), (int32_t)ak.size(), fk.data(), ak.data()};
         CrRenderParams p{(int32_t)c.samples, 0, (int32_t)c.samples, (int32_t)c.max_depth, seed, (int32_t)c.frame, real_type,
-                         c.frame_rate, c.shutter_angle, 0, 0};
+                         c.frame_rate, c.shutter_angle, 0, refit_boxes ? 1 : 0};
         size_t n = (size_t)c.image_width * c.image_height * 3;
         std::vector<double> buf(n);   // large enough for either scalar type
         int32_t rc = cr_render_host(h, &cd, &p, buf.data(), stats);

@@ -2,7 +2,8 @@
 //   --file/-f NAME  --world/-w N  [--threads/-t N (accepted, unused: the GPU replaces the pool)]
 //   [--movie/-m --seconds/-s S --rate/-r R]
 // Extras (not in the reference): --width, --samples, --seed, --scene-seed, --real f32|f64, --device,
-// --bvh reference|sah (the tree cr_upload_scene builds; reference = the parity mode, default),
+// --bvh reference|sah (the tree cr_upload_scene builds; reference = the parity mode, default), --refit (re-derive
+// the wrapper boxes per frame so keyframed primitives are not clipped; the reference does not),
 // --dump-desc FILE (write the flattened scene description and exit; used by the tests to check
 // this mirror against the Python one).
 #include "crucible.hpp"
@@ -33,6 +34,7 @@ int main(int argc, char** argv) {
     uint64_t seed = 0xC0FFEE, scene_seed = 1;
     int device = 0;
     std::string bvh = "reference";
+    bool refit = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char* { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
@@ -49,6 +51,7 @@ int main(int argc, char** argv) {
         else if (a == "--real") real = next();
         else if (a == "--device") device = atoi(next());
         else if (a == "--bvh") bvh = next();
+        else if (a == "--refit") refit = true;
         else if (a == "--dump-desc") dump = next();
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
@@ -82,6 +85,7 @@ int main(int argc, char** argv) {
         scene.real_type = real == "f64" ? CR_REAL_F64 : CR_REAL_F32;
         if (bvh != "reference" && bvh != "sah") { fprintf(stderr, "--bvh takes reference or sah\n"); return 2; }
         scene.bvh_mode = bvh == "sah" ? CR_BVH_SAH : CR_BVH_REFERENCE;
+        scene.refit_boxes = refit;
         if (!dump.empty()) { dump_desc(scene.flatten(), dump.c_str()); return 0; }
         CrStats st;
         memset(&st, 0, sizeof st);

@@ -207,6 +207,7 @@ class Camera:
         self.samples, self.max_depth = 10, 10
         self.thread_count = thread_count
         self.frame_rate, self.frame, self.shutter_angle = float(frame_rate), 0, float(shutter_angle)
+        self.refit_boxes = False   # True: CrRenderParams.refit_boxes (wrapper boxes follow keyframed primitives)
 
     def next_frame(self):
         self.frame += 1
@@ -258,7 +259,7 @@ class Camera:
     def params(self, seed, real_type, sample_begin=0, sample_count=None, output_sum=False):
         n = self.samples if sample_count is None else sample_count
         return A.CrRenderParams(self.samples, sample_begin, n, self.max_depth, seed, self.frame, real_type,
-                                self.frame_rate, self.shutter_angle, 1 if output_sum else 0, 0)
+                                self.frame_rate, self.shutter_angle, 1 if output_sum else 0, 1 if self.refit_boxes else 0)
 
 
 # ------------------------------------------------------------------ scene

@@ -213,7 +213,11 @@ typedef struct CrRenderParams {
     double shutter_angle;
     int32_t output_sum;     /* 0: per-pixel mean over `samples` (average_samples,
                                ray_casting.rs:154-173); 1: raw per-pixel sum of this shard */
-    int32_t _pad;
+    int32_t refit_boxes;    /* 0: wrapper boxes stay the construction-time boxes, as in the reference
+                               (bvhwrapper.rs:47-50) -- keyframed primitives are clipped where they leave them;
+                               1: SURVEY 8(f) rows 1-2: boxes are re-derived on the device for this frame's
+                               ray-time interval before the render (crucible_amd/csrc/refit.hpp), so moving
+                               primitives are intersected wherever they are.  No effect without primitive keys. */
 } CrRenderParams;
 
 /*

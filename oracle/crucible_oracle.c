@@ -339,6 +339,7 @@ typedef struct Hittable {
     Timeline tl;             /* sphere: centre+radius; triangle: vertex a (b, c below) */
     real vb[3], vc[3];
     Aabb bbox;
+    Aabb bbox0;              /* wrappers: the construction-time box (refit_boxes = 0 restores it) */
     struct Hittable* left;   /* BVHWrapper, bvhwrapper.rs:7-11 */
     struct Hittable* right;
     struct Hittable** objs;  /* HitList, hitlist.rs:7-10 */
@@ -561,6 +562,7 @@ static void scene_build_world(Scene* sc) {
         Hittable* root = bvh_generate(sc, vis, tmp, 0, n_vis);
         root->bbox = aabb_from_boxes(root->left->bbox, root->right->bbox);   /* new_from_vec :39 */
         sc->world = root;
+        for (int i = 0; i < sc->pool_used; i++) sc->pool[i].bbox0 = sc->pool[i].bbox;
     }
     free(vis); free(tmp);
 }
@@ -793,6 +795,7 @@ EXPORT void oracle_scene_destroy(Scene* sc) {
     if (!sc) return;
     for (int i = 0; i < sc->n_images; i++) free(sc->images[i].rgb);
     free(sc->images); free(sc->prims); free(sc->materials); free(sc->textures); free(sc->keys); free(sc->pool);
+    free(sc->empty_list.objs);
     free(sc);
 }
 
@@ -847,6 +850,77 @@ EXPORT Scene* oracle_scene_create(const CrSceneDesc* d) {
     return sc;
 }
 
+/* ------------------------------------------------------------------ refit_boxes (not in the reference)
+ * CrRenderParams.refit_boxes = 1, the rule of crucible_amd/csrc/refit.hpp restated: a primitive's box over the
+ * frame's ray times [ta, tb] is the union of its construction-rule box (sphere_bbox / triangle_bbox) at ta, tb,
+ * every key end inside (ta, tb) and every key start inside (ta, tb] with the key active and not yet active; a
+ * wrapper's box is aabb_from_boxes of its children.  The reference never recomputes wrapper boxes
+ * (bvhwrapper.rs:47-50,102-106), so this mode is pinned by construction only: against the linear list
+ * (oracle_use_list) it must give the same closest hits. */
+static void timeline_eval_side(const Timeline* tl, real t, int before_start, int is_sphere, real out[4]) {
+    real x = R(0.0) + tl->init[0], y = R(0.0) + tl->init[1], z = R(0.0) + tl->init[2];
+    real w = tl->init[3];
+    for (int i = 0; i < tl->n_keys; i++) {
+        const Key* k = &tl->keys[i];
+        int started = before_start ? (k->t0 < t) : (k->t0 <= t);
+        int active = (t > k->t1) || (started && t <= k->t1);
+        if (!active) continue;
+        real s = key_scaled_time(k, t);
+        if (k->channel <= CR_KEY_TZ) {
+            real val = (k->interp == CR_KEY_LERP) ? k->a * s : k->a;
+            if (k->channel == CR_KEY_TX) x = x + val;
+            else if (k->channel == CR_KEY_TY) y = y + val;
+            else z = z + val;
+        } else if (k->channel == CR_KEY_RADIUS) {
+            w = (k->interp == CR_KEY_LERP) ? k->a + (k->b - k->a) * s : k->a;
+        }
+    }
+    if (is_sphere) { out[0] = x; out[1] = y; out[2] = z; out[3] = w; }
+    else { out[0] = w * x; out[1] = w * y; out[2] = w * z; out[3] = w; }
+}
+static Aabb prim_box_at(const Hittable* h, real t, int before_start) {
+    if (h->kind == H_SPHERE) {
+        real sp[4];
+        timeline_eval_side(&h->tl, t, before_start, 1, sp);
+        return sphere_bbox(v3(sp[0], sp[1], sp[2]), sp[3]);
+    }
+    real pa[4], pb[4], pc[4];
+    Timeline tlb = h->tl, tlc = h->tl;
+    tlb.init[0] = h->vb[0]; tlb.init[1] = h->vb[1]; tlb.init[2] = h->vb[2];
+    tlc.init[0] = h->vc[0]; tlc.init[1] = h->vc[1]; tlc.init[2] = h->vc[2];
+    timeline_eval_side(&h->tl, t, before_start, 0, pa);
+    timeline_eval_side(&tlb, t, before_start, 0, pb);
+    timeline_eval_side(&tlc, t, before_start, 0, pc);
+    return triangle_bbox(v3(pa[0], pa[1], pa[2]), v3(pb[0], pb[1], pb[2]), v3(pc[0], pc[1], pc[2]));
+}
+static Aabb prim_box_over(const Hittable* h, real ta, real tb) {
+    Aabb b = prim_box_at(h, ta, 0);
+    if (h->tl.n_keys == 0) return b;
+    b = aabb_from_boxes(b, prim_box_at(h, tb, 0));
+    for (int i = 0; i < h->tl.n_keys; i++) {
+        const Key* k = &h->tl.keys[i];
+        if (ta < k->t0 && k->t0 <= tb) {
+            b = aabb_from_boxes(b, prim_box_at(h, k->t0, 0));
+            b = aabb_from_boxes(b, prim_box_at(h, k->t0, 1));
+        }
+        if (ta < k->t1 && k->t1 < tb) b = aabb_from_boxes(b, prim_box_at(h, k->t1, 0));
+    }
+    return b;
+}
+static Aabb refit_rec(Hittable* h, real ta, real tb) {
+    if (h->kind != H_BVH) return prim_box_over(h, ta, tb);
+    Aabb l = refit_rec(h->left, ta, tb);
+    Aabb r = h->right == h->left ? l : refit_rec(h->right, ta, tb);
+    h->bbox = aabb_from_boxes(l, r);
+    return h->bbox;
+}
+/* choose the boxes this render walks: refitted to [ta, tb], or the construction-time ones */
+static void scene_prepare_boxes(Scene* sc, int refit, real ta, real tb) {
+    if (sc->world->kind != H_BVH) return;
+    for (int i = 0; i < sc->pool_used; i++) sc->pool[i].bbox = sc->pool[i].bbox0;
+    if (refit) (void)refit_rec(sc->world, ta, tb);
+}
+
 typedef struct {
     const Scene* sc; const Camera* cam; const CrRenderParams* p;
     real* out; int64_t pix_begin, pix_end;
@@ -882,6 +956,11 @@ EXPORT int32_t oracle_render(const Scene* sc, const CrCameraDesc* cd, const CrRe
     Camera cam;
     camera_setup(&cam, cd);
     if (n_threads < 1) n_threads = 1;
+    {   /* the boxes of this frame (one render at a time per scene, as the library's handle) */
+        real current_time = (real)p->frame * (R(1.0) / (real)p->frame_rate);
+        real shutter_length = ((real)p->shutter_angle / R(360.0)) * (R(1.0) / (real)p->frame_rate);
+        scene_prepare_boxes((Scene*)sc, p->refit_boxes, current_time, current_time + shutter_length);
+    }
     volatile int64_t next = pix_begin;
     Job* jobs = (Job*)calloc((size_t)n_threads, sizeof(Job));
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
@@ -1078,6 +1157,7 @@ EXPORT int32_t oracle_set_tree(Scene* sc, const double* boxes, const int32_t* ki
         w->bbox.x.min = (real)b[0]; w->bbox.x.max = (real)b[1];
         w->bbox.y.min = (real)b[2]; w->bbox.y.max = (real)b[3];
         w->bbox.z.min = (real)b[4]; w->bbox.z.max = (real)b[5];
+        w->bbox0 = w->bbox;
         w->left = kids[2 * i] >= 0 ? &pool[kids[2 * i]] : &sc->prims[~kids[2 * i]];
         w->right = kids[2 * i + 1] >= 0 ? &pool[kids[2 * i + 1]] : &sc->prims[~kids[2 * i + 1]];
     }
@@ -1085,6 +1165,18 @@ EXPORT int32_t oracle_set_tree(Scene* sc, const double* boxes, const int32_t* ki
     sc->pool = pool; sc->pool_used = n; sc->pool_cap = n;
     sc->world = &pool[0];
     return 0;
+}
+
+/* Replace the world by the flat list of visible primitives (HitList::hit, hitlist.rs:51-65: a linear closest-hit
+ * scan with no boxes at all): the ground truth a refitted tree must agree with. */
+EXPORT void oracle_use_list(Scene* sc) {
+    Hittable* l = &sc->empty_list;
+    free(l->objs);
+    memset(l, 0, sizeof *l);
+    l->kind = H_HITLIST;
+    l->objs = (Hittable**)malloc(sizeof(Hittable*) * (size_t)(sc->n_prims + 1));
+    for (int i = 0; i < sc->n_prims; i++) if (!sc->prims[i].hide) l->objs[l->n_objs++] = &sc->prims[i];
+    sc->world = l;
 }
 
 EXPORT int32_t oracle_bvh_dump(const Scene* sc, real* boxes, int32_t* kids, int32_t cap) {

@@ -76,6 +76,8 @@ class Oracle:
         L.oracle_bvh_dump.argtypes = [P, P, P, C.c_int32]
         L.oracle_set_tree.argtypes = [P, P, P, C.c_int32]
         L.oracle_set_tree.restype = C.c_int32
+        L.oracle_use_list.argtypes = [P]
+        L.oracle_use_list.restype = None
 
     # ---- helpers
     def arr(self, x):
@@ -122,12 +124,16 @@ class Oracle:
         assert rc == 0, rc
         return out, st.as_dict()
 
-    def render_image(self, scene, *, seed, n_threads=None, tree=None, **kw):
+    def render_image(self, scene, *, seed, n_threads=None, tree=None, linear_list=False, **kw):
+        """tree: walk this exported wrapper tree; linear_list: no BVH at all (HitList::hit over the visible
+        primitives) -- the ground truth for closest hits."""
         flat = scene.flatten()
         h = self.scene_create(flat)
         try:
             if tree is not None:
                 self.set_tree(h, *tree)
+            if linear_list:
+                self.lib.oracle_use_list(h)
             out, st = self.render(h, scene.scene_cam, seed=seed, n_threads=n_threads, **kw)
         finally:
             self.scene_destroy(h)

@@ -72,3 +72,39 @@ def few_spheres(n, width=48, samples=3):
         x = (k - (n - 1) / 2.0) * 1.3
         sc.add_element(Sphere.new((x, 0.5 + 0.1 * (k % 3), -0.2 * k), 0.5, mats[k % len(mats)]), f"s{k}")
     return sc
+
+
+def moving_scene(width=96, samples=6, frame=0, null_motion=False, depth=8):
+    """Keyframed primitives that leave their construction-time boxes: 1 fps with a 360 degree shutter, so frame f
+    draws ray times in [f, f + 1].  A sphere sweeping 6 units (LERP), one jumping mid-shutter (NERP), one growing
+    (radius LERP) then snapping small (radius NERP), a late mover (frame 2), a moving triangle pair, static
+    neighbours.  null_motion: the same keys with zero offsets / unchanged radii (refit must then change nothing)."""
+    sc = Scene.new_image(16.0 / 9.0, width, 1, 360.0, 1)
+    cam = sc.scene_cam
+    cam.set_samples(samples)
+    cam.set_max_depth(depth)
+    cam.look_from((0.0, 3.0, 9.0))
+    cam.look_at((0.0, 0.7, 0.0))
+    cam.set_vfov(35.0)
+    cam.frame = frame
+    k = 0.0 if null_motion else 1.0
+    ground = Lambertian.new_from_texture(CheckerTexture.new_from_color(0.8, (0.2, 0.3, 0.1), (0.9, 0.9, 0.9)), 1.0)
+    sc.add_element(Sphere.new((0.0, -100.0, 0.0), 100.0, ground), "ground")
+    sc.add_element(Sphere.new((-3.0, 0.5, 0.0), 0.5, Lambertian.new_from_color((0.8, 0.2, 0.2), 1.0)), "runner")
+    sc.add_element(Sphere.new((0.0, 0.5, -2.0), 0.5, Metal.new((0.8, 0.8, 0.9), 0.05)), "jumper")
+    sc.add_element(Sphere.new((2.5, 0.3, 1.5), 0.3, Lambertian.new_from_color((0.2, 0.3, 0.8), 1.0)), "grower")
+    sc.add_element(Sphere.new((-2.0, 0.4, 2.5), 0.4, Dielectric.new(1.5)), "late")
+    sc.add_element(Sphere.new((3.5, 0.6, -1.0), 0.6, Metal.new((0.9, 0.7, 0.3), 0.2)), "still_a")
+    sc.add_element(Sphere.new((-4.0, 0.7, -1.5), 0.7, Lambertian.new_from_color((0.3, 0.7, 0.3), 1.0)), "still_b")
+    m_tri = Metal.new((0.7, 0.7, 0.9), 0.1)
+    sc.add_element(Triangle.new((-1.0, 0.0, 3.0), (0.0, 0.0, 3.2), (-0.5, 1.2, 3.1), m_tri), "tri_a")
+    sc.add_element(Triangle.new((0.0, 0.0, 3.2), (1.0, 0.0, 3.0), (0.5, 1.2, 3.1), m_tri), "tri_b")
+    sc.translate_point((6.0 * k, 0.0, 0.0), 1.0, LERP, LOCAL, "runner")
+    sc.translate_point((0.0, 1.5 * k, 0.5 * k), 0.5, NERP, LOCAL, "jumper")
+    sc.scale_r(0.3 + 0.9 * k, 0.75, LERP, "grower")
+    sc.scale_r(0.3 + 0.2 * k, 1.5, NERP, "grower")
+    sc.translate_point((0.0, 0.0, -3.0 * k), 2.0, NERP, LOCAL, "late")
+    sc.translate_point((4.0 * k, 0.5 * k, 0.0), 3.0, LERP, LOCAL, "late")
+    for alias in ("tri_a", "tri_b"):
+        sc.translate_point((1.5 * k, 0.8 * k, -1.0 * k), 1.0, LERP, LOCAL, alias)
+    return sc

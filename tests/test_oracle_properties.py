@@ -248,3 +248,30 @@ def test_camera_ray_geometry(o):
     r = math.hypot(out[0], out[1])
     assert out[7] >= 5 and (out[7] - 3) % 2 == 0 and r <= 5.0 * math.tan(math.radians(5.0)) + 1e-6 and out[2] == 5   # lens disk
     assert 0.0 <= out[6] <= (180.0 / 360.0) / 24.0                       # time in [0, shutter_length]
+
+
+@pytest.mark.parametrize("frame", [0, 2])
+def test_refit_boxes_rule_against_the_linear_list(o64, frame):
+    """refit_boxes (not in the reference; crucible_amd/csrc/refit.hpp): with the wrapper boxes re-derived for the
+    frame, the BVH gives the linear list's closest hits (HitList::hit, no boxes); with the reference's stale
+    construction-time boxes (bvhwrapper.rs:47-50) the moving primitives are clipped."""
+    import scenes
+    sc = scenes.moving_scene(96, 3, frame=frame)
+    sc.scene_cam.refit_boxes = False
+    truth, tst = o64.render_image(sc, seed=9, linear_list=True)
+    stale, _ = o64.render_image(sc, seed=9)
+    sc.scene_cam.refit_boxes = True
+    fitted, fst = o64.render_image(sc, seed=9)
+    assert (fitted == truth).all(axis=2).mean() >= 0.995
+    assert (stale == truth).all(axis=2).mean() < 0.97
+    assert fst["segments"] == pytest.approx(tst["segments"], rel=2e-3)
+
+
+def test_refit_boxes_identity_without_motion(o64):
+    import scenes
+    sc = scenes.moving_scene(64, 2, frame=0, null_motion=True)
+    sc.scene_cam.refit_boxes = False
+    a, sa = o64.render_image(sc, seed=9)
+    sc.scene_cam.refit_boxes = True
+    b, sb = o64.render_image(sc, seed=9)
+    assert np.array_equal(a, b) and sa["node_tests"] == sb["node_tests"]
