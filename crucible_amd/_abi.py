@@ -10,7 +10,7 @@ CR_PRIM_HIDDEN = 1
 CR_MAT_LAMBERTIAN, CR_MAT_METAL, CR_MAT_DIELECTRIC = 0, 1, 2
 CR_TEX_SOLID, CR_TEX_CHECKER, CR_TEX_IMAGE = 0, 1, 2
 CR_SKY_DEFAULT, CR_SKY_SPHERICAL = 0, 1
-CR_BVH_REFERENCE, CR_BVH_SAH = 0, 1
+CR_BVH_REFERENCE, CR_BVH_SAH, CR_BVH_SAH_ORDERED = 0, 1, 2
 CR_KEY_TX, CR_KEY_TY, CR_KEY_TZ, CR_KEY_RADIUS = 0, 1, 2, 3
 CR_KEY_NERP, CR_KEY_LERP = 0, 1
 
@@ -79,7 +79,8 @@ SYMBOLS = {
                                      C.POINTER(CrStats)]),
     "cr_render_host": (C.c_int32, [C.c_void_p, C.POINTER(CrCameraDesc), C.POINTER(CrRenderParams), C.c_void_p,
                                    C.POINTER(CrStats)]),
-    "cr_export_bvh": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "cr_export_bvh": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                  C.POINTER(C.c_int32)]),
     "cr_last_kernel_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double)]),
     "cr_synchronize": (C.c_int32, [C.c_void_p]),
     "cr_stream": (C.c_void_p, [C.c_void_p]),

@@ -50,6 +50,9 @@ template <typename real> struct DevScene {
     size_t lds_bytes = 0;
     bool animated = false;
     DevBuf entries_refit;                    // working copy whose boxes refit_level_kernel rewrites per frame
+    bool ordered = false;                    // CR_BVH_SAH_ORDERED: `entries` holds EntryO records
+    size_t entry_bytes = sizeof(Entry<real>);
+    std::vector<int8_t> host_axis;           // ordered: split axis per wrapper (-1 leaf), same order as host_entries
     std::vector<int32_t> level_begin;        // entries of tree level l are [level_begin[l], level_begin[l+1])
     std::vector<Entry<real>> host_entries;   // what the device walks (for cr_export_bvh)
     std::vector<int32_t> leaf_desc;          // leaf-order position -> index in the caller's primitive list
@@ -197,7 +200,8 @@ template <typename real> struct Builder {
 // i + 1 and `skip` already names the next wrapper after the subtree; storing the tree level by level
 // (stable in DFS order within a level) puts the top of the tree first, which is what a partial LDS
 // copy wants.  The walk order is unchanged: it follows the links, not the storage order.
-template <typename real> void relayout_bfs(std::vector<Entry<real>>& entries, std::vector<int32_t>& level_begin) {
+template <typename real>
+void relayout_bfs(std::vector<Entry<real>>& entries, std::vector<int32_t>& level_begin, std::vector<int8_t>* axis = nullptr) {
     const int32_t n = (int32_t)entries.size();
     level_begin.assign(1, 0);
     if (n == 0) return;
@@ -223,6 +227,11 @@ template <typename real> void relayout_bfs(std::vector<Entry<real>>& entries, st
         out[k] = e;
     }
     entries.swap(out);
+    if (axis && !axis->empty()) {
+        std::vector<int8_t> ax(n);
+        for (int32_t k = 0; k < n; k++) ax[k] = (*axis)[order_idx[k]];
+        axis->swap(ax);
+    }
 }
 
 // SURVEY 8(f) row 1 -- CR_BVH_SAH: a binned surface-area-heuristic builder (16 bins per axis on the
@@ -236,7 +245,7 @@ template <typename real> struct SahBuilder {
     const std::vector<real>* bmin;   // [3]
     const std::vector<real>* bmax;   // [3]
     std::vector<int32_t>* order;
-    struct Node { real b[6]; int32_t left, right, start, end; };
+    struct Node { real b[6]; int32_t left, right, start, end, axis; };
     std::vector<Node> nodes;
     std::atomic<int32_t> next{0};
     static constexpr int kBins = 16;
@@ -255,7 +264,7 @@ template <typename real> struct SahBuilder {
     void build(int32_t ni, int32_t start, int32_t end, int depth) {
         std::vector<int32_t>& ord = *order;
         Node nd;
-        nd.left = nd.right = -1; nd.start = start; nd.end = end;
+        nd.left = nd.right = -1; nd.start = start; nd.end = end; nd.axis = 0;
         real lo[3], hi[3];
         double clo[3], chi[3];
         for (int a = 0; a < 3; a++) { lo[a] = r_inf(real(0)); hi[a] = -r_inf(real(0)); clo[a] = INFINITY; chi[a] = -INFINITY; }
@@ -325,6 +334,7 @@ template <typename real> struct SahBuilder {
         }
         nd.left = next.fetch_add(2);
         nd.right = nd.left + 1;
+        nd.axis = best_axis < 0 ? 0 : best_axis;   // the left child holds the lower centroids along this axis
         nodes[ni] = nd;
         if (depth < 4 && span >= (1 << 15)) {   // the halves touch disjoint ranges of `order` and distinct nodes
             std::thread t([&] { build(nd.left, start, mid, depth + 1); });
@@ -337,8 +347,8 @@ template <typename real> struct SahBuilder {
     }
 
     // Node graph -> pre-order wrapper array with skip links (the layout Builder emits).
-    void linearise(std::vector<Entry<real>>& out) const {
-        out.clear();
+    void linearise(std::vector<Entry<real>>& out, std::vector<int8_t>& axis) const {
+        out.clear(); axis.clear();
         std::vector<int32_t> stack{0}, open;   // open: pre-order indices of inner wrappers awaiting their end
         std::vector<std::pair<int32_t, int32_t>> todo;   // (node, pre-order index of the parent) -- iterative DFS
         struct Frame { int32_t node; int32_t state; int32_t idx; };
@@ -351,8 +361,8 @@ template <typename real> struct SahBuilder {
                 Entry<real> e;
                 for (int k = 0; k < 6; k++) e.b[k] = nd.b[k];
                 e.skip = f.idx + 1; e.leaf = -1;
-                if (nd.left < 0) { e.leaf = (nd.start << 1) | (nd.end - nd.start - 1); out.push_back(e); fr.pop_back(); continue; }
-                out.push_back(e);
+                if (nd.left < 0) { e.leaf = (nd.start << 1) | (nd.end - nd.start - 1); out.push_back(e); axis.push_back(-1); fr.pop_back(); continue; }
+                out.push_back(e); axis.push_back((int8_t)nd.axis);
                 f.state = 1;
                 fr.push_back({nd.left, 0, -1});
             } else if (f.state == 1) {
@@ -401,12 +411,14 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
             }
         }
     }
-    if (n > 0 && h->bvh_mode == CR_BVH_SAH) {
+    std::vector<int8_t> axis;
+    ds.ordered = h->bvh_mode == CR_BVH_SAH_ORDERED;
+    if (n > 0 && h->bvh_mode != CR_BVH_REFERENCE) {
         SahBuilder<real> sb;
         sb.bmin = b.bmin; sb.bmax = b.bmax; sb.order = &b.order;
         sb.build_root(n);
-        sb.linearise(b.entries);
-        relayout_bfs(b.entries, ds.level_begin);
+        sb.linearise(b.entries, axis);
+        relayout_bfs(b.entries, ds.level_begin, &axis);
     } else if (n > 0) { b.build_root(n); relayout_bfs(b.entries, ds.level_begin); }
     else ds.level_begin.assign(1, 0);
     std::vector<Prim<real>> leaf_prims(n);
@@ -471,6 +483,29 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
         if (bytes) return hipMemcpy(d.p, src_p, bytes, hipMemcpyHostToDevice);
         return hipSuccess;
     };
+    ds.entry_bytes = ds.ordered ? sizeof(EntryO<real>) : sizeof(Entry<real>);
+    if (ds.ordered) {   // per-octant skip links, parents before children (level order)
+        const int32_t ne = (int32_t)b.entries.size();
+        std::vector<EntryO<real>> eo((size_t)ne);
+        for (int32_t i = 0; i < ne; i++) {
+            for (int k = 0; k < 6; k++) eo[i].b[k] = b.entries[i].b[k];
+            eo[i].unused = 0;
+            const int32_t leaf = b.entries[i].leaf;
+            eo[i].leaf = leaf < 0 ? -((-leaf) * 4 + axis[i]) : leaf;
+        }
+        if (ne > 0) for (int o = 0; o < 8; o++) eo[0].skip[o] = ne;
+        for (int32_t i = 0; i < ne; i++) {
+            const int32_t leaf = b.entries[i].leaf;
+            if (leaf >= 0) continue;
+            const int32_t left = -leaf;
+            for (int o = 0; o < 8; o++) {
+                const int32_t nearc = left + ((o >> axis[i]) & 1), farc = left + 1 - ((o >> axis[i]) & 1);
+                eo[nearc].skip[o] = farc;
+                eo[farc].skip[o] = eo[i].skip[o];
+            }
+        }
+        HIP_TRY(h, up(ds.entries, eo.data(), eo.size() * sizeof(EntryO<real>)));
+    } else
     HIP_TRY(h, up(ds.entries, b.entries.data(), b.entries.size() * sizeof(Entry<real>)));
     HIP_TRY(h, up(ds.prims, leaf_prims.data(), leaf_prims.size() * sizeof(Prim<real>)));
     HIP_TRY(h, up(ds.mats, mats.data(), mats.size() * sizeof(Mat<real>)));
@@ -479,10 +514,11 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
     ds.n_entries = (int32_t)b.entries.size(); ds.n_prims = n; ds.n_mats = (int32_t)mats.size(); ds.n_texs = (int32_t)texs.size();
     ds.n_scene_keys = (int32_t)h->keys.size();
     auto r16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    ds.lds_bytes = r16(b.entries.size() * sizeof(Entry<real>)) + r16(leaf_prims.size() * sizeof(Prim<real>)) +
+    ds.lds_bytes = r16(b.entries.size() * ds.entry_bytes) + r16(leaf_prims.size() * sizeof(Prim<real>)) +
                    r16(mats.size() * sizeof(Mat<real>)) + r16(texs.size() * sizeof(Tex<real>));
     ds.animated = any_keys;
     ds.host_entries = b.entries;
+    ds.host_axis = axis;
     ds.leaf_desc.resize(n);
     for (int32_t i = 0; i < n; i++) ds.leaf_desc[i] = vis[b.order[i]];
     ds.built = true;
@@ -494,11 +530,11 @@ template <typename real> void key_to_real(const CrKeyframe& k, Key<real>& o) {
     o.t0 = (real)k.t0; o.t1 = (real)k.t1; o.a = (real)k.a; o.b = (real)k.b; o.channel = k.channel; o.interp = k.interp;
 }
 
-template <typename real, int RES, bool ANIM>
+template <typename real, int RES, bool ANIM, bool ORD = false>
 int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, CrStats* stats) {
     constexpr bool LDS = RES != RES_GLOBAL;
     KernelArgs<real> args = args_in;
-    auto kern = pathtrace_kernel<real, RES, ANIM>;
+    auto kern = pathtrace_kernel<real, RES, ANIM, ORD>;
     if (LDS) HIP_TRY(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     // Workgroup size: the candidate that keeps the most waves resident per CU (a larger
     // workgroup shares one LDS copy of the scene among more waves); ties go to the larger.
@@ -802,15 +838,18 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     a.shutter_length = ((real)p->shutter_angle / real(360)) * (real(1) / (real)p->frame_rate);   // :79
     a.output_sum = p->output_sum;
     if (refit) {   // refit.hpp: wrapper boxes for this frame's ray times [current_time, current_time + shutter_length]
-        const size_t bytes = (size_t)ds.n_entries * sizeof(Entry<real>);
+        const size_t bytes = (size_t)ds.n_entries * ds.entry_bytes;
         HIP_TRY(h, ds.entries_refit.ensure(bytes));
         HIP_TRY(h, hipMemcpyAsync(ds.entries_refit.p, ds.entries.p, bytes, hipMemcpyDeviceToDevice, h->stream));
         for (size_t l = ds.level_begin.size() - 1; l-- > 0;) {
             const int32_t begin = ds.level_begin[l], end = ds.level_begin[l + 1];
             if (end <= begin) continue;
-            hipLaunchKernelGGL((refit_level_kernel<real>), dim3((unsigned)((end - begin + 255) / 256)), dim3(256), 0, h->stream,
-                               (Entry<real>*)ds.entries_refit.p, begin, end, (const Prim<real>*)ds.prims.p, (const Key<real>*)ds.keys.p,
-                               a.current_time, a.current_time + a.shutter_length);
+            const dim3 grid((unsigned)((end - begin + 255) / 256)), block(256);
+            const real ta = a.current_time, tb = a.current_time + a.shutter_length;
+            if (ds.ordered) hipLaunchKernelGGL((refit_level_kernel<real, true>), grid, block, 0, h->stream, (EntryO<real>*)ds.entries_refit.p,
+                                               begin, end, (const Prim<real>*)ds.prims.p, (const Key<real>*)ds.keys.p, ta, tb);
+            else hipLaunchKernelGGL((refit_level_kernel<real, false>), grid, block, 0, h->stream, (Entry<real>*)ds.entries_refit.p,
+                                    begin, end, (const Prim<real>*)ds.prims.p, (const Key<real>*)ds.keys.p, ta, tb);
         }
         HIP_TRY(h, hipGetLastError());
         a.entries = (const Entry<real>*)ds.entries_refit.p;
@@ -823,6 +862,21 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     a.walk_round_steps = (uint32_t)h->walk_round_steps;
 
     const bool anim = ds.animated || c.animated;
+    if (ds.ordered) {   // near-child-first walk: megakernel only
+        if (h->pipeline != 0) return fail(h, CR_ERR_UNSUPPORTED, "CR_BVH_SAH_ORDERED is implemented by the megakernel pipeline only");
+        if (ds.n_entries > 0 && ds.lds_bytes <= h->lds_limit) {
+            a.lds_entries = ds.n_entries;
+            return anim ? launch<real, RES_LDS, true, true>(h, a, ds.lds_bytes, stats) : launch<real, RES_LDS, false, true>(h, a, ds.lds_bytes, stats);
+        }
+        const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, h->lds_top_bytes / sizeof(EntryO<real>));
+        if (top > 0) {
+            a.lds_entries = top;
+            const size_t bytes = (size_t)top * sizeof(EntryO<real>);
+            return anim ? launch<real, RES_TOP, true, true>(h, a, bytes, stats) : launch<real, RES_TOP, false, true>(h, a, bytes, stats);
+        }
+        a.lds_entries = 0;
+        return anim ? launch<real, RES_GLOBAL, true, true>(h, a, 0, stats) : launch<real, RES_GLOBAL, false, true>(h, a, 0, stats);
+    }
     if (h->pipeline == 1) return render_wavefront<real>(h, a, ds, anim, stats);
     if (h->pipeline == 2) {   // LDS-queue megakernel when scene + slot arrays fit in LDS, else the plain megakernel below
         const size_t budget = 160 * 1024, state = queue_state_bytes<real>();
@@ -883,7 +937,7 @@ uint32_t display_byte(double c) {   // impl Display for Color, utils.rs:422-437:
 // wrapper = box + left/right child) in walk order.  A leaf wrapper of one primitive holds it twice, as the
 // reference's span-1 wrappers do (bvhwrapper.rs:58-60).
 template <typename real>
-int32_t export_bvh(CrHandle* h, double* boxes, int32_t* children, int32_t capacity, int32_t* n_out) {
+int32_t export_bvh(CrHandle* h, double* boxes, int32_t* children, int32_t* split_axis, int32_t capacity, int32_t* n_out) {
     int32_t rc = build_dev_scene<real>(h);
     if (rc != CR_OK) return rc;
     const DevScene<real>& ds = dev_scene<real>(h);
@@ -900,6 +954,7 @@ int32_t export_bvh(CrHandle* h, double* boxes, int32_t* children, int32_t capaci
         if (f.state == 0) {
             f.out = n++;
             for (int k = 0; k < 6; k++) boxes[6 * f.out + k] = (double)e.b[k];
+            if (split_axis) split_axis[f.out] = (ds.ordered && e.leaf < 0) ? (int32_t)ds.host_axis[f.entry] : -1;
             if (e.leaf >= 0) {
                 const int32_t first = e.leaf >> 1, count = (e.leaf & 1) + 1;
                 children[2 * f.out] = ~ds.leaf_desc[first];
@@ -1024,7 +1079,7 @@ int32_t cr_upload_scene(CrHandle* h, const CrSceneDesc* s) {
         if (p.kind == CR_PRIM_SPHERE && !(p.v[3] >= 0.0)) return fail(h, CR_ERR_INVALID_ARG, "Cannot make a sphere with negative radius");   // sphere.rs:26
     }
     if (s->sky_kind != CR_SKY_DEFAULT && s->sky_kind != CR_SKY_SPHERICAL) return fail(h, CR_ERR_INVALID_ARG, "unknown sky kind");
-    if (s->bvh_mode != CR_BVH_REFERENCE && s->bvh_mode != CR_BVH_SAH) return fail(h, CR_ERR_INVALID_ARG, "unknown bvh_mode");
+    if (s->bvh_mode != CR_BVH_REFERENCE && s->bvh_mode != CR_BVH_SAH && s->bvh_mode != CR_BVH_SAH_ORDERED) return fail(h, CR_ERR_INVALID_ARG, "unknown bvh_mode");
     if (s->sky_kind == CR_SKY_SPHERICAL && (s->sky_image < 0 || s->sky_image >= s->n_images)) return fail(h, CR_ERR_INVALID_ARG, "sky image index out of range");
     for (int i = 0; i < s->n_images; i++)
         if (s->images[i].width < 1 || s->images[i].height < 1 || !s->images[i].rgb8) return fail(h, CR_ERR_INVALID_ARG, "bad image");
@@ -1111,14 +1166,15 @@ static int32_t check_queue_abort(CrHandle* h) {
     return CR_OK;
 }
 
-int32_t cr_export_bvh(CrHandle* h, int32_t real_type, double* boxes, int32_t* children, int32_t capacity, int32_t* n_wrappers) {
+int32_t cr_export_bvh(CrHandle* h, int32_t real_type, double* boxes, int32_t* children, int32_t* split_axis, int32_t capacity,
+                      int32_t* n_wrappers) {
     if (!h) return CR_ERR_INVALID_ARG;
     if (!n_wrappers) return fail(h, CR_ERR_INVALID_ARG, "cr_export_bvh: null n_wrappers");
     if (!h->has_scene) return fail(h, CR_ERR_NO_SCENE, "cr_export_bvh before cr_upload_scene");
     if (real_type != CR_REAL_F32 && real_type != CR_REAL_F64) return fail(h, CR_ERR_INVALID_ARG, "unknown real_type");
     HIP_TRY(h, hipSetDevice(h->device));
-    return real_type == CR_REAL_F64 ? export_bvh<double>(h, boxes, children, capacity, n_wrappers)
-                                    : export_bvh<float>(h, boxes, children, capacity, n_wrappers);
+    return real_type == CR_REAL_F64 ? export_bvh<double>(h, boxes, children, split_axis, capacity, n_wrappers)
+                                    : export_bvh<float>(h, boxes, children, split_axis, capacity, n_wrappers);
 }
 
 int32_t cr_last_kernel_ms(CrHandle* h, double* out_ms) {

@@ -140,6 +140,23 @@ template <typename real> struct alignas(16) Entry {
     int32_t skip;
     int32_t leaf;
 };
+// CR_BVH_SAH_ORDERED: the same wrapper with one skip link per ray-direction octant, so the walk can take the
+// child on the ray's side of the split first and still be stackless.  Siblings are adjacent in the level-order
+// array, hence an inner wrapper stores only its left child and the split axis: leaf = -(left * 4 + axis), and the
+// near child of a ray with octant bits oct (bit a set: direction[a] < 0) is left + ((oct >> axis) & 1).
+// skip[oct] = the wrapper to visit after this subtree under that octant's order.  The head (b, leaf) overlays
+// Entry's, so a refit or an export can read either.
+template <typename real> struct alignas(16) EntryO {
+    real b[6];
+    int32_t unused;
+    int32_t leaf;
+    int32_t skip[8];
+};
+template <typename real, bool ORD> struct EntryOf { using type = Entry<real>; };
+template <typename real> struct EntryOf<real, true> { using type = EntryO<real>; };
+CR_HD int32_t ordered_left(int32_t leaf) { return (-leaf) >> 2; }
+CR_HD int32_t ordered_near(int32_t leaf, int32_t oct) { const int32_t v = -leaf; return (v >> 2) + ((oct >> (v & 3)) & 1); }
+
 // Primitive record in leaf order.  g[0..3] sphere centre+radius, or g[0..8] a,b,c.
 template <typename real> struct alignas(16) Prim {
     real g[9];
@@ -549,6 +566,21 @@ CR_D Entry<real> fetch_entry(const Entry<real>* lds, const Entry<real>* glob, in
     if (RES == RES_TOP) return idx < lds_entries ? lds[idx] : glob[idx];
     return glob[idx];
 }
+// The ordered layout read into the same record: skip = the link of the ray's octant.
+template <typename real, int RES>
+CR_D Entry<real> fetch_entry_ordered(const Entry<real>* lds, const Entry<real>* glob, int32_t lds_entries, int32_t idx, int32_t oct) {
+    auto rd = [&](const EntryO<real>* p) {
+        const EntryO<real>& s = p[idx];
+        Entry<real> e;
+        for (int k = 0; k < 6; k++) e.b[k] = s.b[k];
+        e.leaf = s.leaf;
+        e.skip = s.skip[oct];
+        return e;
+    };
+    if (RES == RES_LDS) return rd((const EntryO<real>*)lds);
+    if (RES == RES_TOP) return idx < lds_entries ? rd((const EntryO<real>*)lds) : rd((const EntryO<real>*)glob);
+    return rd((const EntryO<real>*)glob);
+}
 
 // The per-ray state of BVHWrapper::hit's walk, kept in registers so a walk can be suspended and resumed.
 template <typename real> struct WalkState {
@@ -558,6 +590,7 @@ template <typename real> struct WalkState {
     int32_t best;        // leaf-order index of that primitive, -1 = none
     int32_t idx;         // next wrapper to visit; n_entries = walk finished
     bool exact_box;      // an infinite 1/dir component: Aabb::hit's compare/select form is required
+    int32_t oct;         // ordered walk: bit a set when direction[a] < 0
 };
 
 template <typename real> CR_D void walk_begin(WalkState<real>& w, V3<real> rd) {
@@ -567,6 +600,7 @@ template <typename real> CR_D void walk_begin(WalkState<real>& w, V3<real> rd) {
     w.exact_box = (r_abs(w.inv.x) == r_inf(real(0))) || (r_abs(w.inv.y) == r_inf(real(0))) || (r_abs(w.inv.z) == r_inf(real(0)));
     w.dd = len2(rd);
     w.idx = 0; w.best_t = r_inf(real(0)); w.best = -1;
+    w.oct = (rd.x < real(0) ? 1 : 0) | (rd.y < real(0) ? 2 : 0) | (rd.z < real(0) ? 4 : 0);
 }
 
 // One round of the while-while walk for the lanes with `walking` set: step through wrappers in the reference's
@@ -574,7 +608,8 @@ template <typename real> CR_D void walk_begin(WalkState<real>& w, V3<real> rd) {
 // or has made `budget` steps (0 = unbounded); then the lanes parked on a leaf intersect its primitives together.
 // Per lane this is exactly BVHWrapper::hit's sequence (bvhwrapper.rs:96-126); the round structure only decides
 // when lanes wait for each other.
-template <typename real, int RES, bool ANIM>
+// ORD: the ordered layout (EntryO behind the same pointers) -- near child first, per-octant skip links.
+template <typename real, int RES, bool ANIM, bool ORD = false>
 CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, const Prim<real>* prims, V3<real> ro, V3<real> rd, real rtime,
                      WalkState<real>& w, bool walking, uint32_t budget, unsigned long long& c_node, uint32_t& c_prim) {
     const real tmin = real(0.001);
@@ -585,19 +620,21 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
             const Pair<real> ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
             const Pair<real> ix = {w.inv.x, w.inv.x}, iy = {w.inv.y, w.inv.y}, iz = {w.inv.z, w.inv.z};
             while (w.idx < n_entries) {
-                const Entry<real> e = fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx);
+                const Entry<real> e = ORD ? fetch_entry_ordered<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx, w.oct)
+                                          : fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx);
                 c_node++;
                 bool hit = box_hit_fast(e.b, ox, oy, oz, ix, iy, iz, tmin, w.best_t);
-                w.idx = (hit && e.leaf < 0) ? -e.leaf : e.skip;
+                w.idx = (hit && e.leaf < 0) ? (ORD ? ordered_near(e.leaf, w.oct) : -e.leaf) : e.skip;
                 if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
                 if (--budget == 0) break;
             }
         } else {
             while (w.idx < n_entries) {
-                const Entry<real> e = fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx);
+                const Entry<real> e = ORD ? fetch_entry_ordered<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx, w.oct)
+                                          : fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx);
                 c_node++;
                 bool hit = box_hit(e.b, ro, w.inv, tmin, w.best_t);
-                w.idx = (hit && e.leaf < 0) ? -e.leaf : e.skip;
+                w.idx = (hit && e.leaf < 0) ? (ORD ? ordered_near(e.leaf, w.oct) : -e.leaf) : e.skip;
                 if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
             }
         }
@@ -649,8 +686,9 @@ template <typename real> struct MaxBlock { static constexpr int value = 1024; };
 // One lane = one pixel at a time, all of that pixel's samples in draw order (so the
 // per-pixel sum is the reference's sequential sum).  Lanes that finish a pixel pull the
 // next pixel index with one wave-aggregated atomic (ballot + prefix count).
-template <typename real, int RES, bool ANIM>
+template <typename real, int RES, bool ANIM, bool ORD = false>
 __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const KernelArgs<real> A) {
+    using EntryT = typename EntryOf<real, ORD>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Entry<real>* lds_entries = nullptr;
     const Prim<real>* prims = A.prims;
@@ -662,10 +700,10 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
             uint32_t* d = (uint32_t*)(smem + off);
             for (size_t i = threadIdx.x; i < bytes / 4; i += blockDim.x) d[i] = s[i];
         };
-        copy(A.entries, 0, (size_t)A.lds_entries * sizeof(Entry<real>));
+        copy(A.entries, 0, (size_t)A.lds_entries * sizeof(EntryT));
         lds_entries = (const Entry<real>*)smem;
         if (RES == RES_LDS) {   // the whole scene: entries | prims | mats | texs, each 16-B aligned
-            size_t o1 = (((size_t)A.n_entries * sizeof(Entry<real>) + 15) & ~(size_t)15);
+            size_t o1 = (((size_t)A.n_entries * sizeof(EntryT) + 15) & ~(size_t)15);
             size_t o2 = o1 + (((size_t)A.n_prims * sizeof(Prim<real>) + 15) & ~(size_t)15);
             size_t o3 = o2 + (((size_t)A.n_mats * sizeof(Mat<real>) + 15) & ~(size_t)15);
             copy(A.prims, o1, (size_t)A.n_prims * sizeof(Prim<real>));
@@ -754,7 +792,7 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
         if (__ballot(state == ST_WALK)) {
             for (;;) {
                 CR_DIAG_ONLY(d_leaf++;)
-                walk_round<real, RES, ANIM>(A, lds_entries, prims, ro, rd, rtime, ws, state == ST_WALK, A.walk_round_steps, c_node, c_prim);
+                walk_round<real, RES, ANIM, ORD>(A, lds_entries, prims, ro, rd, rtime, ws, state == ST_WALK, A.walk_round_steps, c_node, c_prim);
                 if (state == ST_WALK && ws.idx >= n_entries) state = ST_SHADE;
                 const uint64_t walking = __ballot(state == ST_WALK);
                 if (!walking || 64u - (uint32_t)__popcll(walking) >= A.walk_exit_lanes) break;

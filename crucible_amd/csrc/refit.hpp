@@ -95,8 +95,8 @@ CR_HD void prim_box_over(const Prim<real>& p, const Key<real>* keys, real ta, re
 #if defined(__HIPCC__)
 // One level of the tree, deepest level first (entries are stored level by level, children after parents):
 // leaves take their primitives' boxes, inner wrappers the union of their two children, already refitted.
-template <typename real>
-__global__ void refit_level_kernel(Entry<real>* entries, int32_t begin, int32_t end, const Prim<real>* prims,
+template <typename real, bool ORD>
+__global__ void refit_level_kernel(typename EntryOf<real, ORD>::type* entries, int32_t begin, int32_t end, const Prim<real>* prims,
                                    const Key<real>* keys, real ta, real tb) {
     const int32_t i = begin + (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= end) return;
@@ -107,10 +107,11 @@ __global__ void refit_level_kernel(Entry<real>* entries, int32_t begin, int32_t 
         const int32_t first = leaf >> 1, count = (leaf & 1) + 1;
         for (int32_t k = 0; k < count; k++) prim_box_over(prims[first + k], keys, ta, tb, lo, hi);
     } else {
-        const Entry<real> l = entries[-leaf];
-        const Entry<real> r = entries[l.skip];   // the wrapper after the left subtree = the right child
-        const real llo[3] = {l.b[0], l.b[2], l.b[4]}, lhi[3] = {l.b[1], l.b[3], l.b[5]};
-        const real rlo[3] = {r.b[0], r.b[2], r.b[4]}, rhi[3] = {r.b[1], r.b[3], r.b[5]};
+        const int32_t li = ORD ? ordered_left(leaf) : -leaf;   // siblings are adjacent in the level-order array
+        const real* l = entries[li].b;
+        const real* r = entries[li + 1].b;
+        const real llo[3] = {l[0], l[2], l[4]}, lhi[3] = {l[1], l[3], l[5]};
+        const real rlo[3] = {r[0], r[2], r[4]}, rhi[3] = {r[1], r[3], r[5]};
         enclose(lo, hi, llo, lhi);
         enclose(lo, hi, rlo, rhi);
     }

@@ -2,7 +2,7 @@
 //   --file/-f NAME  --world/-w N  [--threads/-t N (accepted, unused: the GPU replaces the pool)]
 //   [--movie/-m --seconds/-s S --rate/-r R]
 // Extras (not in the reference): --width, --samples, --seed, --scene-seed, --real f32|f64, --device,
-// --bvh reference|sah (the tree cr_upload_scene builds; reference = the parity mode, default), --refit (re-derive
+// --bvh reference|sah|ordered (the tree cr_upload_scene builds; reference = the parity mode, default), --refit (re-derive
 // the wrapper boxes per frame so keyframed primitives are not clipped; the reference does not),
 // --dump-desc FILE (write the flattened scene description and exit; used by the tests to check
 // this mirror against the Python one).
@@ -83,8 +83,8 @@ int main(int argc, char** argv) {
         }();
         scene.seed = seed; scene.device = device;
         scene.real_type = real == "f64" ? CR_REAL_F64 : CR_REAL_F32;
-        if (bvh != "reference" && bvh != "sah") { fprintf(stderr, "--bvh takes reference or sah\n"); return 2; }
-        scene.bvh_mode = bvh == "sah" ? CR_BVH_SAH : CR_BVH_REFERENCE;
+        if (bvh != "reference" && bvh != "sah" && bvh != "ordered") { fprintf(stderr, "--bvh takes reference, sah or ordered\n"); return 2; }
+        scene.bvh_mode = bvh == "sah" ? CR_BVH_SAH : (bvh == "ordered" ? CR_BVH_SAH_ORDERED : CR_BVH_REFERENCE);
         scene.refit_boxes = refit;
         if (!dump.empty()) { dump_desc(scene.flatten(), dump.c_str()); return 0; }
         CrStats st;

@@ -95,14 +95,17 @@ class Renderer:
         return st.as_dict() if want_stats else None
 
     def export_bvh(self, real_type=A.CR_REAL_F32):
-        """The wrapper tree the device walks: (boxes (n, 6) f64, children (n, 2) i32), see cr_export_bvh."""
+        """The wrapper tree the device walks: (boxes (n, 6) f64, children (n, 2) i32, split_axis (n,) i32), see
+        cr_export_bvh."""
         n = C.c_int32()
-        self._check(self.lib.cr_export_bvh(self.h, real_type, None, None, 0, C.byref(n)))
+        self._check(self.lib.cr_export_bvh(self.h, real_type, None, None, None, 0, C.byref(n)))
         boxes = np.zeros((max(1, n.value), 6), dtype=np.float64)
         kids = np.zeros((max(1, n.value), 2), dtype=np.int32)
+        axis = np.full(max(1, n.value), -1, dtype=np.int32)
         self._check(self.lib.cr_export_bvh(self.h, real_type, boxes.ctypes.data_as(C.c_void_p),
-                                           kids.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
-        return boxes[:n.value], kids[:n.value]
+                                           kids.ctypes.data_as(C.c_void_p), axis.ctypes.data_as(C.c_void_p), n.value,
+                                           C.byref(n)))
+        return boxes[:n.value], kids[:n.value], axis[:n.value]
 
     def last_kernel_ms(self):
         ms = C.c_double()

@@ -149,8 +149,14 @@ typedef struct CrKeyframe {
  *                     ray grazes a box face (Aabb::hit's `max <= min` miss, bvh.rs:96-132), so
  *                     images are not guaranteed bit-identical to CR_BVH_REFERENCE; cr_export_bvh
  *                     hands a checker the exact tree.
+ *   CR_BVH_SAH_ORDERED CR_BVH_SAH's tree walked near child first: at an inner wrapper the child on the ray's
+ *                     side of the split (the left one when direction[axis] >= 0) is visited before the other,
+ *                     which then sees the interval already shrunk.  Not BVHWrapper::hit's order (always left
+ *                     then right); the closest hit again differs from the reference tree's only on box-grazing
+ *                     rays.  Stackless on the device (one skip link per direction octant).  Megakernel
+ *                     pipeline only.
  */
-enum { CR_BVH_REFERENCE = 0, CR_BVH_SAH = 1 };
+enum { CR_BVH_REFERENCE = 0, CR_BVH_SAH = 1, CR_BVH_SAH_ORDERED = 2 };
 
 typedef struct CrSceneDesc {
     int32_t n_prims;
@@ -160,7 +166,7 @@ typedef struct CrSceneDesc {
     int32_t n_keys;
     int32_t sky_kind;
     int32_t sky_image;
-    int32_t bvh_mode;       /* CR_BVH_REFERENCE (0) | CR_BVH_SAH */
+    int32_t bvh_mode;       /* CR_BVH_REFERENCE (0) | CR_BVH_SAH | CR_BVH_SAH_ORDERED */
     const CrPrimitive* prims;
     const CrMaterial* materials;
     const CrTexture* textures;
@@ -271,10 +277,12 @@ CR_API int32_t cr_render_host(CrHandle* h, const CrCameraDesc* cam, const CrRend
  * wrapper k has boxes[6k..6k+5] = xmin,xmax,ymin,ymax,zmin,zmax (exact values of `real_type`) and
  * children[2k], children[2k+1] = left, right: >= 0 another wrapper's index, < 0 the bitwise complement of a
  * primitive's index in CrSceneDesc.prims.  Wrappers are numbered in walk order (root 0, left subtree, right
- * subtree); a one-primitive wrapper names that primitive twice (bvhwrapper.rs:58-60).  *n_wrappers receives the
- * count; boxes/children may be NULL to query it.  Builds the tree if the scene was not rendered yet. */
-CR_API int32_t cr_export_bvh(CrHandle* h, int32_t real_type, double* boxes, int32_t* children, int32_t capacity,
-                             int32_t* n_wrappers);
+ * subtree); a one-primitive wrapper names that primitive twice (bvhwrapper.rs:58-60).  split_axis (may be NULL)
+ * receives, per wrapper, the axis whose direction sign picks the child visited first in CR_BVH_SAH_ORDERED mode
+ * (right child first when direction[axis] < 0), or -1 where the order is always left then right.  *n_wrappers
+ * receives the count; boxes/children may be NULL to query it.  Builds the tree if the scene was not rendered yet. */
+CR_API int32_t cr_export_bvh(CrHandle* h, int32_t real_type, double* boxes, int32_t* children, int32_t* split_axis,
+                             int32_t capacity, int32_t* n_wrappers);
 
 /* Wait for the last render launched on this handle and return its kernel time in
  * milliseconds, measured with HIP events recorded on the handle's stream around the

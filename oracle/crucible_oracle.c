@@ -340,6 +340,8 @@ typedef struct Hittable {
     real vb[3], vc[3];
     Aabb bbox;
     Aabb bbox0;              /* wrappers: the construction-time box (refit_boxes = 0 restores it) */
+    int near_axis;           /* wrappers: 0 = BVHWrapper::hit's order (left, right); k+1 = CR_BVH_SAH_ORDERED: the right
+                                child first when direction[k] < 0 (not in the reference; set by oracle_set_tree only) */
     struct Hittable* left;   /* BVHWrapper, bvhwrapper.rs:7-11 */
     struct Hittable* right;
     struct Hittable** objs;  /* HitList, hitlist.rs:7-10 */
@@ -477,11 +479,16 @@ static int bvh_hit(Hittable* b, const Ray* r, Interval ray_t, HitRecord* rec, Co
     cn->node_tests++;
     if (!aabb_hit(&b->bbox, r, ray_t)) return 0;
     HitRecord hl, hr;
-    int hit_left = hittable_hit(b->left, r, ray_t, &hl, cn);
+    Hittable *first = b->left, *second = b->right;
+    if (b->near_axis) {
+        const real d = b->near_axis == 1 ? r->direction.x : (b->near_axis == 2 ? r->direction.y : r->direction.z);
+        if (d < R(0.0)) { first = b->right; second = b->left; }
+    }
+    int hit_left = hittable_hit(first, r, ray_t, &hl, cn);
     Interval right_t = {ray_t.min, hit_left ? hl.t : ray_t.max};
     /* a span-1 wrapper holds the same object twice; the reference tests it twice */
     if (b->left == b->right && b->left->kind != H_BVH && b->left->kind != H_HITLIST) cn->prim_tests_dedup--;
-    int hit_right = hittable_hit(b->right, r, right_t, &hr, cn);
+    int hit_right = hittable_hit(second, r, right_t, &hr, cn);
     if (hit_right) { *rec = hr; return 1; }
     if (hit_left) { *rec = hl; return 1; }
     return 0;
@@ -1140,10 +1147,11 @@ static int dump_rec(const Scene* sc, const Hittable* h, real* boxes, int32_t* ki
 }
 /* Replace the scene's wrapper tree by a given one (the shape cr_export_bvh writes: per wrapper 6 doubles
  * xmin,xmax,ymin,ymax,zmin,zmax and (left,right): >= 0 wrapper index, < 0 ~index of a primitive in the
- * desc list; wrapper 0 is the root).  The walk stays BVHWrapper::hit (bvhwrapper.rs:96-126); only the
- * topology and boxes are the caller's.  Used to check the library's CR_BVH_SAH mode: the reference builds
+ * desc list; wrapper 0 is the root; split_axis NULL or per wrapper -1 | the axis of CR_BVH_SAH_ORDERED's
+ * near-child-first rule).  The walk stays BVHWrapper::hit (bvhwrapper.rs:96-126) -- with split_axis, except for
+ * which child goes first; only the topology and boxes are the caller's.  Used to check the library's CR_BVH_SAH mode: the reference builds
  * no such tree, so that mode is pinned only by this walk.  Returns 0, or -1 on a malformed tree. */
-EXPORT int32_t oracle_set_tree(Scene* sc, const double* boxes, const int32_t* kids, int32_t n) {
+EXPORT int32_t oracle_set_tree(Scene* sc, const double* boxes, const int32_t* kids, const int32_t* split_axis, int32_t n) {
     if (n <= 0) return -1;
     for (int i = 0; i < 2 * n; i++) {
         if (kids[i] >= n || (kids[i] >= 0 && kids[i] <= i / 2)) return -1;   /* children come after their parent */
@@ -1158,6 +1166,7 @@ EXPORT int32_t oracle_set_tree(Scene* sc, const double* boxes, const int32_t* ki
         w->bbox.y.min = (real)b[2]; w->bbox.y.max = (real)b[3];
         w->bbox.z.min = (real)b[4]; w->bbox.z.max = (real)b[5];
         w->bbox0 = w->bbox;
+        w->near_axis = (split_axis && split_axis[i] >= 0 && split_axis[i] <= 2) ? split_axis[i] + 1 : 0;
         w->left = kids[2 * i] >= 0 ? &pool[kids[2 * i]] : &sc->prims[~kids[2 * i]];
         w->right = kids[2 * i + 1] >= 0 ? &pool[kids[2 * i + 1]] : &sc->prims[~kids[2 * i + 1]];
     }

@@ -74,7 +74,7 @@ class Oracle:
         L.oracle_rng_uniforms.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, P]
         L.oracle_rng_u64.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, P]
         L.oracle_bvh_dump.argtypes = [P, P, P, C.c_int32]
-        L.oracle_set_tree.argtypes = [P, P, P, C.c_int32]
+        L.oracle_set_tree.argtypes = [P, P, P, P, C.c_int32]
         L.oracle_set_tree.restype = C.c_int32
         L.oracle_use_list.argtypes = [P]
         L.oracle_use_list.restype = None
@@ -101,11 +101,13 @@ class Oracle:
     def scene_destroy(self, h):
         self.lib.oracle_scene_destroy(h)
 
-    def set_tree(self, scene_h, boxes, kids):
+    def set_tree(self, scene_h, boxes, kids, axis=None):
         """Walk this wrapper tree (cr_export_bvh's output) instead of the reference-built one."""
         boxes = np.ascontiguousarray(boxes, dtype=np.float64)
         kids = np.ascontiguousarray(kids, dtype=np.int32)
-        rc = self.lib.oracle_set_tree(scene_h, boxes.ctypes.data, kids.ctypes.data, len(kids))
+        axis = None if axis is None else np.ascontiguousarray(axis, dtype=np.int32)
+        rc = self.lib.oracle_set_tree(scene_h, boxes.ctypes.data, kids.ctypes.data,
+                                      None if axis is None else axis.ctypes.data, len(kids))
         assert rc == 0, "malformed wrapper tree"
 
     def render(self, scene_h, cam, *, seed, sample_begin=0, sample_count=None, output_sum=False, pix_begin=0,

@@ -40,7 +40,8 @@ def visible(flat):
 def test_export_reference_mode_is_the_oracle_tree(renderer, oracles, rt, tag, build):
     sc = build()
     flat = upload(renderer, sc, A.CR_BVH_REFERENCE)
-    boxes, kids = renderer.export_bvh(rt)
+    boxes, kids, axis = renderer.export_bvh(rt)
+    assert (axis == -1).all()
     o = oracles[rt]
     h = o.scene_create(flat)
     try:
@@ -81,11 +82,17 @@ def check_tree(boxes, kids, vis):
 @pytest.mark.parametrize("build", [lambda: book1_end_scene(1, scene_seed=2, image_width=32, samples=1),
                                    lambda: scenes.mixed_scene(32, 1), lambda: scenes.few_spheres(3),
                                    lambda: scenes.few_spheres(9)], ids=["book1", "mixed", "three", "nine"])
-def test_sah_tree_is_well_formed(renderer, rt, tag, build):
+@pytest.mark.parametrize("mode", [A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED], ids=["sah", "ordered"])
+def test_sah_tree_is_well_formed(renderer, rt, tag, build, mode):
     sc = build()
-    flat = upload(renderer, sc, A.CR_BVH_SAH)
-    boxes, kids = renderer.export_bvh(rt)
+    flat = upload(renderer, sc, mode)
+    boxes, kids, axis = renderer.export_bvh(rt)
     check_tree(boxes, kids, visible(flat))
+    inner = kids[:, 0] >= 0
+    if mode == A.CR_BVH_SAH_ORDERED:
+        assert ((axis[inner] >= 0) & (axis[inner] <= 2)).all() and (axis[~inner] == -1).all()
+    else:
+        assert (axis == -1).all()
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
@@ -97,9 +104,10 @@ def test_sah_tree_is_well_formed(renderer, rt, tag, build):
     ("few2", lambda: scenes.few_spheres(2), SEED), ("few3", lambda: scenes.few_spheres(3), SEED),
     ("few9", lambda: scenes.few_spheres(9), SEED),
 ])
-def test_sah_mode_bit_exact_against_oracle_on_the_same_tree(renderer, oracles, rt, tag, name, build, seed):
+@pytest.mark.parametrize("mode", [A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED], ids=["sah", "ordered"])
+def test_sah_mode_bit_exact_against_oracle_on_the_same_tree(renderer, oracles, rt, tag, name, build, seed, mode):
     sc = build()
-    flat = upload(renderer, sc, A.CR_BVH_SAH)
+    flat = upload(renderer, sc, mode)
     img, st = renderer.render(sc.scene_cam, seed=seed, real_type=rt)
     tree = renderer.export_bvh(rt) if visible(flat) else None
     ref, rst = oracles[rt].render_image(sc, seed=seed, tree=tree)
@@ -108,13 +116,15 @@ def test_sah_mode_bit_exact_against_oracle_on_the_same_tree(renderer, oracles, r
         assert st[k] == rst[k], (k, st[k], rst[k])
     if tree is not None:
         assert st["bvh_entries"] == len(tree[1])
+    print(name, tag, mode, "node tests", st["node_tests"])
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
-def test_sah_teapot_against_oracle(renderer, oracles, rt, tag):
+@pytest.mark.parametrize("mode", [A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED], ids=["sah", "ordered"])
+def test_sah_teapot_against_oracle(renderer, oracles, rt, tag, mode):
     """6320 triangles + image sky: libm carve-out as in test_gpu_parity (acos/atan2/asin), so 1e-4 on >= 99.9 %."""
     sc = load_teapot(1, image_width=96, samples=2, sky=procedural_sky(256, 128))
-    upload(renderer, sc, A.CR_BVH_SAH)
+    upload(renderer, sc, mode)
     img, st = renderer.render(sc.scene_cam, seed=5, real_type=rt)
     ref, rst = oracles[rt].render_image(sc, seed=5, tree=renderer.export_bvh(rt))
     d = np.abs(img.astype(np.float64) - ref.astype(np.float64)).max(axis=2)
@@ -124,12 +134,13 @@ def test_sah_teapot_against_oracle(renderer, oracles, rt, tag):
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
-def test_sah_agrees_with_reference_topology(renderer, rt, tag):
+@pytest.mark.parametrize("mode", [A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED], ids=["sah", "ordered"])
+def test_sah_agrees_with_reference_topology(renderer, rt, tag, mode):
     """Same closest hits except for rays grazing a box face: nearly all pixels identical, far fewer box tests."""
     sc = book1_end_scene(1, scene_seed=1, image_width=320, samples=8)
     upload(renderer, sc, A.CR_BVH_REFERENCE)
     ref, rst = renderer.render(sc.scene_cam, seed=SEED, real_type=rt)
-    upload(renderer, sc, A.CR_BVH_SAH)
+    upload(renderer, sc, mode)
     img, st = renderer.render(sc.scene_cam, seed=SEED, real_type=rt)
     same = (img == ref).all(axis=2).mean()
     assert same >= 0.995, same

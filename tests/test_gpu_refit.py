@@ -27,12 +27,12 @@ def render(renderer, sc, rt, mode, refit):
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
-@pytest.mark.parametrize("mode", [A.CR_BVH_REFERENCE, A.CR_BVH_SAH], ids=["reference", "sah"])
+@pytest.mark.parametrize("mode", [A.CR_BVH_REFERENCE, A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED], ids=["reference", "sah", "ordered"])
 @pytest.mark.parametrize("frame", [0, 1, 2, 5])
 def test_refit_bit_exact_against_oracle_refit(renderer, oracles, rt, tag, mode, frame):
     sc = scenes.moving_scene(96, 4, frame=frame)
     img, st = render(renderer, sc, rt, mode, True)
-    tree = renderer.export_bvh(rt) if mode == A.CR_BVH_SAH else None
+    tree = renderer.export_bvh(rt) if mode != A.CR_BVH_REFERENCE else None
     ref, rst = oracles[rt].render_image(sc, seed=SEED, tree=tree)
     assert np.array_equal(img, ref), f"differing px = {(img != ref).any(axis=2).sum()}"
     for k in COUNTERS:
@@ -40,12 +40,12 @@ def test_refit_bit_exact_against_oracle_refit(renderer, oracles, rt, tag, mode, 
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
-@pytest.mark.parametrize("mode", [A.CR_BVH_REFERENCE, A.CR_BVH_SAH], ids=["reference", "sah"])
+@pytest.mark.parametrize("mode", [A.CR_BVH_REFERENCE, A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED], ids=["reference", "sah", "ordered"])
 def test_stale_boxes_still_match_the_oracle(renderer, oracles, rt, tag, mode):
     """refit_boxes = 0 on the same scene: the reference's (clipped) image, bit-exact as before."""
     sc = scenes.moving_scene(96, 4, frame=0)
     img, st = render(renderer, sc, rt, mode, False)
-    tree = renderer.export_bvh(rt) if mode == A.CR_BVH_SAH else None
+    tree = renderer.export_bvh(rt) if mode != A.CR_BVH_REFERENCE else None
     ref, rst = oracles[rt].render_image(sc, seed=SEED, tree=tree)
     assert np.array_equal(img, ref)
     for k in COUNTERS:
@@ -68,7 +68,7 @@ def test_refit_agrees_with_the_linear_list_and_stale_boxes_do_not(renderer, orac
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
-@pytest.mark.parametrize("mode", [A.CR_BVH_REFERENCE, A.CR_BVH_SAH], ids=["reference", "sah"])
+@pytest.mark.parametrize("mode", [A.CR_BVH_REFERENCE, A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED], ids=["reference", "sah", "ordered"])
 def test_refit_of_motionless_keys_changes_nothing(renderer, rt, tag, mode):
     """Keys with zero offsets: the refit kernels run (the scene has primitive keys) and must reproduce the
     construction-time boxes exactly."""
