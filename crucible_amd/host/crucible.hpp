@@ -12,6 +12,8 @@
 // Nothing here computes pixels: Scene::flatten() produces the CrSceneDesc the library consumes and
 // Scene::render_scene() is Camera::render over cr_upload_scene / cr_render_host / cr_write_ppm.
 #pragma once
+#include <thread>
+#include <cstring>
 #include "../../include/crucible_hip.h"
 
 #include <algorithm>
@@ -105,9 +107,73 @@ public:
 };
 
 // ---------------------------------------------------------------- textures, materials
-struct RTWImage {   // decoded RGB8 (img_loader.rs:17-55); decoding itself is out of scope (third-party codecs)
+struct RTWImage {   // decoded RGB8 (img_loader.rs:17-55)
     int width = 0, height = 0;
     std::vector<uint8_t> rgb8;
+
+    // Radiance .hdr (RGBE) files -- the format of the reference's garden.hdr skybox
+    // (demo_images.rs:223-242).  The reference decodes through the `image` crate and keeps 8 bits
+    // (`to_rgb8()`, img_loader.rs:24-28): float = mantissa * 2^(e - 136) (0 when e == 0), then
+    // round(clamp(x, 0, 1) * 255).  The crate is not vendored, so this conversion is parity unpinned.
+    // Flat, new-style (per-channel) RLE and old-style repeat-marker scanlines; -Y/+Y H +X W orientations.
+    static std::shared_ptr<RTWImage> load_hdr(const std::string& path) {
+        FILE* fp = fopen(path.c_str(), "rb");
+        if (!fp) throw std::runtime_error("Could not open image " + path);
+        std::vector<uint8_t> d;
+        uint8_t chunk[65536];
+        for (size_t n; (n = fread(chunk, 1, sizeof chunk, fp)) > 0;) d.insert(d.end(), chunk, chunk + n);
+        fclose(fp);
+        size_t pos = 0;
+        auto line = [&]() { std::string l; while (pos < d.size() && d[pos] != '\n') l.push_back((char)d[pos++]); pos++; return l; };
+        std::string magic = line();
+        if (magic.rfind("#?", 0) != 0) throw std::runtime_error("not a Radiance file: " + path);
+        for (;;) { if (pos >= d.size()) throw std::runtime_error("truncated Radiance header"); if (line().empty()) break; }
+        char sy = 0, sx = 0, ay = 0, ax = 0;
+        int H = 0, W = 0;
+        std::string res = line();
+        if (sscanf(res.c_str(), "%c%c %d %c%c %d", &sy, &ay, &H, &sx, &ax, &W) != 6 || ay != 'Y' || ax != 'X' || sx != '+' || W < 1 || H < 1)
+            throw std::runtime_error("unsupported Radiance resolution line: " + res);
+        auto im = std::make_shared<RTWImage>();
+        im->width = W; im->height = H; im->rgb8.resize((size_t)W * H * 3);
+        std::vector<uint8_t> sl((size_t)W * 4);
+        auto need = [&](size_t n) { if (pos + n > d.size()) throw std::runtime_error("truncated Radiance data"); };
+        for (int row = 0; row < H; row++) {
+            need(4);
+            if (W >= 8 && W < 32768 && d[pos] == 2 && d[pos + 1] == 2 && ((d[pos + 2] << 8) | d[pos + 3]) == W) {
+                pos += 4;
+                for (int c = 0; c < 4; c++)
+                    for (int x = 0; x < W;) {
+                        need(1);
+                        int n = d[pos++];
+                        if (n > 128) { n -= 128; need(1); if (x + n > W) throw std::runtime_error("bad Radiance run"); uint8_t v = d[pos++]; for (int k = 0; k < n; k++) sl[(size_t)(x++) * 4 + c] = v; }
+                        else { if (n == 0 || x + n > W) throw std::runtime_error("bad Radiance run"); need((size_t)n); for (int k = 0; k < n; k++) sl[(size_t)(x++) * 4 + c] = d[pos++]; }
+                    }
+            } else {   // flat pixels, with old-style repeat markers (1,1,1,count)
+                int shift = 0;
+                for (int x = 0; x < W;) {
+                    need(4);
+                    const uint8_t* q = &d[pos]; pos += 4;
+                    if (q[0] == 1 && q[1] == 1 && q[2] == 1 && x > 0) {
+                        long n = (long)q[3] << shift;
+                        if (x + n > W) throw std::runtime_error("bad Radiance run");
+                        for (long k = 0; k < n; k++, x++) memcpy(&sl[(size_t)x * 4], &sl[(size_t)(x - 1) * 4], 4);
+                        shift += 8;
+                    } else { memcpy(&sl[(size_t)x * 4], q, 4); x++; shift = 0; }
+                }
+            }
+            const int out_row = sy == '-' ? row : H - 1 - row;   // -Y: top row first
+            for (int x = 0; x < W; x++) {
+                const uint8_t* q = &sl[(size_t)x * 4];
+                const float f = q[3] ? std::ldexp(1.0f, (int)q[3] - 136) : 0.0f;
+                for (int c = 0; c < 3; c++) {
+                    float v = (float)q[c] * f;
+                    v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+                    im->rgb8[((size_t)out_row * W + x) * 3 + c] = (uint8_t)std::lround(v * 255.0f);
+                }
+            }
+        }
+        return im;
+    }
 };
 struct Textures;
 using TexturePtr = std::shared_ptr<Textures>;   // Arc<Textures>
@@ -292,6 +358,7 @@ public:
     int real_type = CR_REAL_F32;
     int bvh_mode = CR_BVH_REFERENCE;   // CR_BVH_SAH: the quality builder (include/crucible_hip.h)
     bool refit_boxes = false;          // CrRenderParams.refit_boxes: wrapper boxes follow keyframed primitives
+    std::string frame_format = "ppm";  // "ppm" (ASCII P3, the reference's) | "p6" | "png"
     int device = 0;
 
     Scene(double aspect, uint32_t width, size_t rate, double shutter, size_t threads)
@@ -381,7 +448,8 @@ public:
     size_t compute_frame_count() const { return (size_t)std::ceil(duration * (double)frame_rate); }   // scene/mod.rs:324-330
 
     // ---- Camera::render over the library (scene/mod.rs:283-347)
-    int32_t render_image(CrHandle* h, const std::string& fname, CrStats* stats = nullptr) const {
+    // The render proper: W*H*3 reals of `real_type` into `buf` (sized for either scalar type).
+    int32_t render_frame(CrHandle* h, std::vector<double>& buf, CrStats* stats = nullptr) const {
         const Camera& c = scene_cam;
         std::vector<CrKeyframe> fk = c.look_from_tl.keyframes(), ak = c.look_at_tl.keyframes();
         CrCameraDesc cd{c.image_width, c.image_height, c.vfov_degrees, c.defocus_angle_degrees, c.focus_dist,
@@ -390,13 +458,24 @@ public:
                         {c.vup.x, c.vup.y, c.vup.z}, (int32_t)fk.size(), (int32_t)ak.size(), fk.data(), ak.data()};
         CrRenderParams p{(int32_t)c.samples, 0, (int32_t)c.samples, (int32_t)c.max_depth, seed, (int32_t)c.frame, real_type,
                          c.frame_rate, c.shutter_angle, 0, refit_boxes ? 1 : 0};
-        size_t n = (size_t)c.image_width * c.image_height * 3;
-        std::vector<double> buf(n);   // large enough for either scalar type
-        int32_t rc = cr_render_host(h, &cd, &p, buf.data(), stats);
-        if (rc != CR_OK) return rc;
-        rc = cr_write_ppm((fname + ".ppm").c_str(), buf.data(), real_type, c.image_width, c.image_height);
-        if (rc == CR_OK) fprintf(stderr, "Successful render! Image stored at: %s.ppm\n", fname.c_str());
+        buf.resize((size_t)c.image_width * c.image_height * 3);
+        return cr_render_host(h, &cd, &p, buf.data(), stats);
+    }
+    // The file: "ppm" = the reference's ASCII P3 (camera/mod.rs:286,306-311); "p6" / "png" = SURVEY 8(f) row 3,
+    // the same per-channel bytes in binary PPM / PNG.
+    int32_t write_frame(const std::string& fname, const std::vector<double>& buf) const {
+        const Camera& c = scene_cam;
+        const std::string path = fname + (frame_format == "png" ? ".png" : ".ppm");
+        int32_t rc = frame_format == "png" ? cr_write_png(path.c_str(), buf.data(), real_type, c.image_width, c.image_height)
+                   : frame_format == "p6" ? cr_write_ppm_binary(path.c_str(), buf.data(), real_type, c.image_width, c.image_height)
+                                          : cr_write_ppm(path.c_str(), buf.data(), real_type, c.image_width, c.image_height);
+        if (rc == CR_OK) fprintf(stderr, "Successful render! Image stored at: %s\n", path.c_str());
         return rc;
+    }
+    int32_t render_image(CrHandle* h, const std::string& fname, CrStats* stats = nullptr) const {
+        std::vector<double> buf;
+        int32_t rc = render_frame(h, buf, stats);
+        return rc == CR_OK ? write_frame(fname, buf) : rc;
     }
     int32_t render_scene(const std::string& fname, CrStats* stats = nullptr) {
         CrHandle* h = nullptr;
@@ -409,12 +488,23 @@ public:
             else {   // render_movie, scene/mod.rs:295-322 (the ffmpeg hand-off is out of scope)
                 if (mkdir(fname.c_str(), 0777) != 0 || mkdir((fname + "/artifacts").c_str(), 0777) != 0) rc = CR_ERR_IO;
                 size_t frames = compute_frame_count(), digits = std::to_string(frames).size();
+                // frame k is encoded and written by a helper thread while frame k+1 renders
+                // (two buffers; the reference formats and writes each frame before starting the next).
+                std::vector<double> bufs[2];
+                std::thread writers[2];
+                int32_t write_rc[2] = {CR_OK, CR_OK};
                 for (size_t fr = 0; rc == CR_OK && fr < frames; fr++) {
+                    const int slot = (int)(fr & 1);
+                    if (writers[slot].joinable()) { writers[slot].join(); if (write_rc[slot] != CR_OK) { rc = write_rc[slot]; break; } }
                     std::string num = std::to_string(fr);
                     num = std::string(digits - num.size(), '0') + num;
-                    rc = render_image(h, fname + "/artifacts/image" + num, stats);
+                    rc = render_frame(h, bufs[slot], stats);
+                    if (rc != CR_OK) break;
+                    const std::string stem = fname + "/artifacts/image" + num;
+                    writers[slot] = std::thread([this, stem, slot, &bufs, &write_rc] { write_rc[slot] = write_frame(stem, bufs[slot]); });
                     scene_cam.next_frame();
                 }
+                for (int k = 0; k < 2; k++) if (writers[k].joinable()) { writers[k].join(); if (rc == CR_OK) rc = write_rc[k]; }
             }
         }
         if (rc != CR_OK) fprintf(stderr, "Render failed. %s\n", cr_last_error(h));
@@ -483,6 +573,17 @@ inline Scene load_teapot(size_t threads, uint32_t image_width = 400, uint32_t sa
     book1_camera(sc.scene_cam, samples, Point3{13, 10, 3});
     sc.load_asset("teapot.obj", "teapot", 0.5, Point3{0, 0, 0}, Materials::metal(Color(0.8, 0.3, 0.5), 0.05));
     sc.add_element(Hittables::sphere(Point3{0, -1000, 0}, 1000.0, checker_ground()), "ground");
+    return sc;
+}
+
+inline Scene garden_skybox(size_t threads, std::shared_ptr<RTWImage> sky, uint32_t image_width = 1920, uint32_t samples = 500) {   // :223-242
+    Scene sc = Scene::new_image(16.0 / 9.0, image_width, 24, 180.0, threads);
+    Camera& cam = sc.scene_cam;
+    cam.set_samples(samples); cam.set_max_depth(50);
+    cam.look_from(Point3{0, 0, -12}); cam.look_at(Point3{0, 0, 0});
+    cam.set_vfov(40.0);
+    sc.add_element(Hittables::sphere(Point3{0, 0, 0}, 2.0, Materials::metal(Color(0.8, 0.8, 0.8), 0.05)), "metal_ball");
+    sc.load_spherical_skybox(sky);
     return sc;
 }
 

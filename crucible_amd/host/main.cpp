@@ -2,6 +2,8 @@
 //   --file/-f NAME  --world/-w N  [--threads/-t N (accepted, unused: the GPU replaces the pool)]
 //   [--movie/-m --seconds/-s S --rate/-r R]
 // Extras (not in the reference): --width, --samples, --seed, --scene-seed, --real f32|f64, --device,
+// --format ppm|p6|png (frame files: the reference's ASCII P3, binary PPM, PNG),
+// --sky FILE.hdr (Radiance map as the spherical skybox; world 5 = demo_images::garden_skybox needs it),
 // --bvh reference|sah|ordered (the tree cr_upload_scene builds; reference = the parity mode, default), --refit (re-derive
 // the wrapper boxes per frame so keyframed primitives are not clipped; the reference does not),
 // --dump-desc FILE (write the flattened scene description and exit; used by the tests to check
@@ -22,6 +24,11 @@ static void dump_desc(const FlatScene& f, const char* path) {
     fwrite(f.materials.data(), sizeof(CrMaterial), f.materials.size(), fp);
     fwrite(f.textures.data(), sizeof(CrTexture), f.textures.size(), fp);
     fwrite(f.keys.data(), sizeof(CrKeyframe), f.keys.size(), fp);
+    for (const CrImage& im : f.images) {
+        int32_t wh[2] = {im.width, im.height};
+        fwrite(wh, sizeof wh, 1, fp);
+        fwrite(im.rgb8, 1, (size_t)im.width * im.height * 3, fp);
+    }
     fclose(fp);
 }
 
@@ -33,7 +40,7 @@ int main(int argc, char** argv) {
     long width = -1, samples = -1;
     uint64_t seed = 0xC0FFEE, scene_seed = 1;
     int device = 0;
-    std::string bvh = "reference";
+    std::string bvh = "reference", sky, format = "ppm";
     bool refit = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -51,6 +58,8 @@ int main(int argc, char** argv) {
         else if (a == "--real") real = next();
         else if (a == "--device") device = atoi(next());
         else if (a == "--bvh") bvh = next();
+        else if (a == "--sky") sky = next();
+        else if (a == "--format") format = next();
         else if (a == "--refit") refit = true;
         else if (a == "--dump-desc") dump = next();
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -76,16 +85,22 @@ int main(int argc, char** argv) {
                 case 1: return demo_builder::book1_end_scene(threads, scene_seed, w, samples > 0 ? (uint32_t)samples : 500);
                 case 2: return demo_builder::checkered_spheres(threads, w, samples > 0 ? (uint32_t)samples : 500);
                 case 3: return demo_builder::load_teapot(threads, w, samples > 0 ? (uint32_t)samples : 200);
+                case 5:
+                    if (sky.empty()) throw std::invalid_argument("world 5 (garden_skybox) needs --sky FILE.hdr: garden.hdr is not shipped");
+                    return demo_builder::garden_skybox(threads, RTWImage::load_hdr(sky), w, samples > 0 ? (uint32_t)samples : 500);
                 default:
-                    fprintf(stderr, "Invalid world number. Selecting default scene\n");   // worlds 4/5 need image decoders (out of scope)
+                    fprintf(stderr, "Invalid world number. Selecting default scene\n");   // world 4 (earth) needs a JPEG decoder (third-party codec)
                     return demo_builder::book1_end_scene(threads, scene_seed, w, samples > 0 ? (uint32_t)samples : 500);
             }
         }();
+        if (!sky.empty() && world != 5) scene.load_spherical_skybox(RTWImage::load_hdr(sky));
         scene.seed = seed; scene.device = device;
         scene.real_type = real == "f64" ? CR_REAL_F64 : CR_REAL_F32;
         if (bvh != "reference" && bvh != "sah" && bvh != "ordered") { fprintf(stderr, "--bvh takes reference, sah or ordered\n"); return 2; }
         scene.bvh_mode = bvh == "sah" ? CR_BVH_SAH : (bvh == "ordered" ? CR_BVH_SAH_ORDERED : CR_BVH_REFERENCE);
         scene.refit_boxes = refit;
+        if (format != "ppm" && format != "p6" && format != "png") { fprintf(stderr, "--format takes ppm, p6 or png\n"); return 2; }
+        scene.frame_format = format;
         if (!dump.empty()) { dump_desc(scene.flatten(), dump.c_str()); return 0; }
         CrStats st;
         memset(&st, 0, sizeof st);

@@ -65,6 +65,8 @@ class RTWImage:
     @classmethod
     def new(cls, filename):
         path = build_asset_path(filename)
+        if path.lower().endswith(".hdr"):
+            return cls(decode_radiance(open(path, "rb").read()))
         from PIL import Image   # the reference uses the `image` crate; decoders may differ by an LSB
         with Image.open(path) as im:
             return cls(np.asarray(im.convert("RGB")))
@@ -74,6 +76,76 @@ class RTWImage:
 
     def height(self):
         return self.rgb8.shape[0]
+
+
+def decode_radiance(data):
+    """Radiance .hdr (RGBE) -> HxWx3 uint8 the way the reference keeps images (`image` crate
+    decode, then `to_rgb8()`, img_loader.rs:24-28): float = mantissa * 2^(e - 136) (0 when e == 0), then
+    round(clamp(x, 0, 1) * 255).  The crate is not vendored: parity unpinned.  Flat, new-style RLE and old-style
+    repeat-marker scanlines; `-Y H +X W` and `+Y H +X W`.  Same decoder as RTWImage::load_hdr in host/crucible.hpp."""
+    pos = 0
+
+    def line():
+        nonlocal pos
+        end = data.index(b"\n", pos)
+        out = data[pos:end]
+        pos = end + 1
+        return out
+
+    if not line().startswith(b"#?"):
+        raise ValueError("not a Radiance file")
+    while line():
+        pass
+    res = line().split()
+    if len(res) != 4 or res[0] not in (b"-Y", b"+Y") or res[2] != b"+X":
+        raise ValueError(f"unsupported Radiance resolution line: {res}")
+    H, W = int(res[1]), int(res[3])
+    buf = np.frombuffer(data, dtype=np.uint8)
+    rgbe = np.zeros((H, W, 4), dtype=np.uint8)
+    for row in range(H):
+        if 8 <= W < 32768 and data[pos] == 2 and data[pos + 1] == 2 and ((data[pos + 2] << 8) | data[pos + 3]) == W:
+            pos += 4
+            for c in range(4):
+                x = 0
+                while x < W:
+                    n = data[pos]
+                    pos += 1
+                    if n > 128:
+                        n -= 128
+                        if x + n > W:
+                            raise ValueError("bad Radiance run")
+                        rgbe[row, x:x + n, c] = data[pos]
+                        pos += 1
+                    else:
+                        if n == 0 or x + n > W:
+                            raise ValueError("bad Radiance run")
+                        rgbe[row, x:x + n, c] = buf[pos:pos + n]
+                        pos += n
+                    x += n
+        else:
+            x, shift = 0, 0
+            while x < W:
+                q = buf[pos:pos + 4]
+                pos += 4
+                if q[0] == 1 and q[1] == 1 and q[2] == 1 and x > 0:
+                    n = int(q[3]) << shift
+                    if x + n > W:
+                        raise ValueError("bad Radiance run")
+                    rgbe[row, x:x + n] = rgbe[row, x - 1]
+                    x += n
+                    shift += 8
+                else:
+                    rgbe[row, x] = q
+                    x += 1
+                    shift = 0
+    if res[0] == b"+Y":
+        rgbe = rgbe[::-1]
+    e = rgbe[..., 3].astype(np.int32)
+    f = np.where(e > 0, np.ldexp(np.float32(1.0), e - 136), np.float32(0.0)).astype(np.float32)
+    v = np.clip(rgbe[..., :3].astype(np.float32) * f[..., None], np.float32(0.0), np.float32(1.0))
+    x = v * np.float32(255.0)
+    r = np.floor(x)
+    return (r + (x - r >= np.float32(0.5))).astype(np.uint8)   # f32::round: halves away from zero
 
 
 class ImageTexture:

@@ -24,8 +24,11 @@ def py_dump(sc):
     f = sc.flatten()
     d = f.desc
     hdr = np.array([d.n_prims, d.n_materials, d.n_textures, d.n_images, d.n_keys, d.sky_kind, d.sky_image], dtype=np.int32).tobytes()
-    return (hdr + bytes(f.prims)[:d.n_prims * C.sizeof(A.CrPrimitive)] + bytes(f.materials)[:d.n_materials * C.sizeof(A.CrMaterial)] +
-            bytes(f.textures)[:d.n_textures * C.sizeof(A.CrTexture)] + bytes(f.keys)[:d.n_keys * C.sizeof(A.CrKeyframe)])
+    out = (hdr + bytes(f.prims)[:d.n_prims * C.sizeof(A.CrPrimitive)] + bytes(f.materials)[:d.n_materials * C.sizeof(A.CrMaterial)] +
+           bytes(f.textures)[:d.n_textures * C.sizeof(A.CrTexture)] + bytes(f.keys)[:d.n_keys * C.sizeof(A.CrKeyframe)])
+    for im in f._image_arrays:
+        out += np.array([im.shape[1], im.shape[0]], dtype=np.int32).tobytes() + im.tobytes()
+    return out
 
 
 @pytest.mark.parametrize("world,build", [(1, lambda: book1_end_scene(1, scene_seed=7)), (2, lambda: checkered_spheres(1)),
@@ -34,6 +37,30 @@ def test_cpp_and_python_mirrors_flatten_identically(cli, tmp_path, world, build)
     out = str(tmp_path / "d.bin")
     subprocess.check_call([cli, "--world", str(world), "--scene-seed", "7", "--dump-desc", out], cwd=ROOT, stderr=subprocess.DEVNULL)
     assert open(out, "rb").read() == py_dump(build())
+
+
+@pytest.mark.parametrize("mode,flip", [("rle", False), ("flat", False), ("old", False), ("rle", True)])
+def test_cpp_and_python_decode_radiance_identically(cli, tmp_path, monkeypatch, mode, flip):
+    """world 5 = demo_images::garden_skybox (demo_images.rs:223-242) with a Radiance map given on the command line:
+    RTWImage::load_hdr (C++) and decode_radiance (Python) must produce the same RGB8 sky."""
+    from test_host_logic import _rgbe_from_float, write_hdr
+    from crucible_amd.demo_builder import garden_skybox
+    from crucible_amd.scene import RTWImage
+    rs = np.random.RandomState(8)
+    img = rs.rand(16, 64, 3) * rs.choice([0.05, 0.7, 2.0], size=(16, 64, 1))
+    img[3, 8:40] = img[3, 8]
+    img[9] = 0.0
+    hdr = str(tmp_path / "sky.hdr")
+    write_hdr(hdr, _rgbe_from_float(img), mode, flip)
+    out = str(tmp_path / "d.bin")
+    subprocess.check_call([cli, "--world", "5", "--sky", hdr, "--dump-desc", out], cwd=ROOT, stderr=subprocess.DEVNULL)
+    monkeypatch.setenv("ASSET_DIR", str(tmp_path) + "/")
+    assert open(out, "rb").read() == py_dump(garden_skybox(1, sky=RTWImage.new("sky.hdr")))
+
+
+def test_cli_world5_needs_a_sky(cli):
+    r = subprocess.run([cli, "--world", "5", "--file", "/tmp/x"], cwd=ROOT, capture_output=True)
+    assert r.returncode == 101 and b"garden.hdr is not shipped" in r.stderr
 
 
 def test_cpp_movie_keyframes_match_python(cli, tmp_path):
@@ -76,3 +103,38 @@ def test_cli_movie_writes_frames(cli, tmp_path):
     assert frames == ["image0.ppm", "image1.ppm"]
     a, b = (open(os.path.join(stem, "artifacts", f)).read() for f in frames)
     assert a != b and a.startswith("P3\n32 18\n255\n")
+
+
+@pytest.mark.gpu
+def test_cli_movie_frame_formats_hold_the_same_pixels(cli, tmp_path):
+    """--format p6 / png, written by the helper thread while the next frame renders: same bytes
+    per channel as the reference's ASCII P3, frame for frame."""
+    import zlib
+    pix = {}
+    for fmt in ("ppm", "p6", "png"):
+        stem = str(tmp_path / fmt)
+        subprocess.check_call([cli, "--file", stem, "--world", "1", "--movie", "--seconds", "1", "--rate", "3", "--width", "32",
+                               "--samples", "2", "--format", fmt], cwd=ROOT)
+        names = sorted(os.listdir(os.path.join(stem, "artifacts")))
+        assert names == [f"image{k}.{'png' if fmt == 'png' else 'ppm'}" for k in range(3)]
+        out = []
+        for n in names:
+            raw = open(os.path.join(stem, "artifacts", n), "rb").read()
+            if fmt == "ppm":
+                out.append(np.array(raw.split()[4:], dtype=np.int64).astype(np.uint8).tobytes())
+            elif fmt == "p6":
+                assert raw.startswith(b"P6\n32 18\n255\n")
+                out.append(raw[len(b"P6\n32 18\n255\n"):])
+            else:
+                assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+                pos, idat = 8, b""
+                while pos < len(raw):
+                    ln = int.from_bytes(raw[pos:pos + 4], "big")
+                    if raw[pos + 4:pos + 8] == b"IDAT":
+                        idat += raw[pos + 8:pos + 8 + ln]
+                    pos += 12 + ln
+                rows = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(18, 1 + 32 * 3)
+                assert (rows[:, 0] == 0).all()        # filter type None on every scanline
+                out.append(rows[:, 1:].tobytes())
+        pix[fmt] = out
+    assert pix["ppm"] == pix["p6"] == pix["png"] and len(set(pix["ppm"])) == 3
