@@ -80,6 +80,7 @@ struct CrHandle {
     DevScene<float> s32;
     DevScene<double> s64;
     DevBuf work_counter, counters, att_stack, out_buf;
+    DevBuf sample_buf, sg_acc;   // sample-granular megakernel: per-sample colours of a batch, running sums between batches
     // wavefront pipeline state (wavefront.hpp)
     DevBuf wf_job, wf_rng, wf_ray, wf_depth, wf_hit_t, wf_hit_prim, wf_chunk, wf_ctrl, wf_samples, wf_acc;
     uint32_t* wf_ring_host = nullptr;   // host-mapped ring the extend kernel reports its queue length into
@@ -92,6 +93,11 @@ struct CrHandle {
     int wf_last_iterations = 0;
     double upload_ms = 0;
     size_t lds_limit = 160 * 1024;
+    // Sample-granular scheduling of the megakernel (pathtrace.hpp, KernelArgs::sg_on): on by default; the per-sample
+    // colour buffer may take up to sample_buf_limit bytes (more samples than fit are rendered in batches).
+    int sample_granular = 1;             // CRUCIBLE_SAMPLE_GRANULAR=0: a lane owns a pixel (no buffer)
+    size_t sample_buf_limit = (size_t)16 << 30;   // CRUCIBLE_SAMPLE_BUF_MB
+    int sg_lw = -1, sg_lh = -1;          // CRUCIBLE_SG_TILE=WxH (powers of two, W*H <= 64); default 4x4 pixels x 4 samples
     size_t lds_top_bytes = 64 * 1024;   // LDS spent on the top of a tree that does not fit whole (CRUCIBLE_LDS_TOP_KB; 0 = none)
     int blocks_per_cu_override = 0;
     int block_override = 0;
@@ -548,20 +554,64 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
     }
     if (best_waves == 0) return fail(h, CR_ERR_HIP, "kernel does not fit on a CU");
     if (h->blocks_per_cu_override > 0) per_cu = h->blocks_per_cu_override;
-    uint32_t total_work = args.tiles_x * args.tiles_y * 64u;
+    // Sample-granular mode: batches of samples whose colours fit the buffer; each batch is one launch of the
+    // path tracer followed by the ordered sum (sg_finalize_kernel).
+    const size_t npix = (size_t)args.cam.W * (size_t)args.cam.H;
+    const int32_t s_begin = args.sample_begin, s_end = args.sample_end;
+    int32_t batch = 0;
+    if (h->sample_granular && s_end > s_begin) {
+        const size_t per_sample = npix * 3 * sizeof(real);
+        batch = (int32_t)std::min<size_t>((size_t)(s_end - s_begin), std::max<size_t>(1, h->sample_buf_limit / per_sample));
+        int lw = h->sg_lw, lh = h->sg_lh;
+        if (lw < 0) { const int ns = batch >= 4 ? 4 : (batch >= 2 ? 2 : 1); lw = ns == 4 ? 2 : 3; lh = ns == 1 ? 3 : 2; }
+        const uint32_t ns = 64u >> (lw + lh);
+        args.sg_lw = (uint32_t)lw; args.sg_lh = (uint32_t)lh;
+        args.tiles_x = ((uint32_t)args.cam.W + (1u << lw) - 1) >> lw;
+        args.tiles_y = ((uint32_t)args.cam.H + (1u << lh) - 1) >> lh;
+        const uint64_t tiles = (uint64_t)args.tiles_x * args.tiles_y;
+        // the 32-bit work counter must hold tiles * groups * 64 plus one chunk per wave
+        const uint64_t max_groups = 0xF0000000ull / (tiles * 64);
+        if (max_groups < 1) batch = 0;
+        else batch = (int32_t)std::min<uint64_t>((uint64_t)batch, max_groups * ns);
+        if (batch > 0 && h->sample_buf.ensure((size_t)batch * per_sample) != hipSuccess) { (void)hipGetLastError(); batch = 0; }
+        if (batch > 0 && batch < s_end - s_begin && h->sg_acc.ensure(per_sample) != hipSuccess) { (void)hipGetLastError(); batch = 0; }
+        if (batch == 0) { args.tiles_x = args_in.tiles_x; args.tiles_y = args_in.tiles_y; }   // fall back: a lane owns a pixel
+    }
+    args.sg_on = batch > 0 ? 1u : 0u;
+    const uint32_t ns = args.sg_on ? (64u >> (args.sg_lw + args.sg_lh)) : 1u;
+    auto groups_of = [&](int32_t n) { return (uint32_t)((n + (int32_t)ns - 1) / (int32_t)ns); };
+    uint64_t total_work = args.sg_on ? (uint64_t)args.tiles_x * args.tiles_y * groups_of(std::min(batch, s_end - s_begin)) * 64u
+                                     : (uint64_t)args.tiles_x * args.tiles_y * 64u;
     uint32_t grid = (uint32_t)(h->n_cus * per_cu);
-    uint32_t need_blocks = (total_work + block - 1) / block;
-    if (grid > need_blocks) grid = need_blocks;
+    uint64_t need_blocks = (total_work + block - 1) / block;
+    if ((uint64_t)grid > need_blocks) grid = (uint32_t)need_blocks;
     if (grid < 1) grid = 1;
     args.n_threads = grid * (uint32_t)block;
     size_t stack_bytes = (size_t)3 * (size_t)(args.max_depth > 0 ? args.max_depth : 1) * args.n_threads * sizeof(real);
     HIP_TRY(h, h->att_stack.ensure(stack_bytes));
     args.att_stack = (real*)h->att_stack.p;
-    HIP_TRY(h, hipMemsetAsync(h->work_counter.p, 0, 4, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 16 * sizeof(uint64_t), h->stream));
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), LDS ? lds_bytes : 0, h->stream, args);
-    HIP_TRY(h, hipGetLastError());
+    if (!args.sg_on) {
+        HIP_TRY(h, hipMemsetAsync(h->work_counter.p, 0, 4, h->stream));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), LDS ? lds_bytes : 0, h->stream, args);
+        HIP_TRY(h, hipGetLastError());
+    } else {
+        args.sample_buf = (real*)h->sample_buf.p;
+        for (int32_t b0 = s_begin; b0 < s_end; b0 += batch) {
+            const int32_t b1 = std::min(s_end, b0 + batch);
+            args.sample_begin = b0; args.sample_end = b1;
+            args.sg_groups = groups_of(b1 - b0);
+            args.sg_total = (uint32_t)((uint64_t)args.tiles_x * args.tiles_y * args.sg_groups * 64u);
+            HIP_TRY(h, hipMemsetAsync(h->work_counter.p, 0, 4, h->stream));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(block), LDS ? lds_bytes : 0, h->stream, args);
+            HIP_TRY(h, hipGetLastError());
+            hipLaunchKernelGGL((sg_finalize_kernel<real>), dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, h->stream, args,
+                               (real*)h->sg_acc.p, b1 - b0, b0 == s_begin ? 1 : 0, b1 == s_end ? 1 : 0);
+            HIP_TRY(h, hipGetLastError());
+        }
+        args.sample_begin = s_begin; args.sample_end = s_end;
+    }
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     h->last_block = block; h->last_grid = (int)grid;
     if (stats) {
@@ -860,6 +910,7 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     a.out = (real*)d_out;
     a.walk_exit_lanes = (uint32_t)h->walk_exit_lanes;
     a.walk_round_steps = (uint32_t)h->walk_round_steps;
+    a.sg_on = 0; a.sg_lw = a.sg_lh = 3; a.sg_groups = 0; a.sg_total = 0; a.sample_buf = nullptr;   // set by launch()
 
     const bool anim = ds.animated || c.animated;
     if (ds.ordered) {   // near-child-first walk: megakernel only
@@ -1005,6 +1056,14 @@ int32_t cr_create(int32_t device_id, CrHandle** out) {
     if ((e = h->work_counter.ensure(16)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = h->counters.ensure(16 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
     if (const char* s = getenv("CRUCIBLE_LDS_LIMIT")) h->lds_limit = (size_t)atol(s);
+    if (const char* s = getenv("CRUCIBLE_SAMPLE_GRANULAR")) h->sample_granular = atoi(s) != 0;
+    if (const char* s = getenv("CRUCIBLE_SAMPLE_BUF_MB")) h->sample_buf_limit = (size_t)std::max(0L, atol(s)) << 20;
+    if (const char* s = getenv("CRUCIBLE_SG_TILE")) {
+        int tw = 0, th = 0;
+        if (sscanf(s, "%dx%d", &tw, &th) == 2 && tw > 0 && th > 0 && (tw & (tw - 1)) == 0 && (th & (th - 1)) == 0 && tw * th <= 64) {
+            h->sg_lw = __builtin_ctz((unsigned)tw); h->sg_lh = __builtin_ctz((unsigned)th);
+        }
+    }
     if (const char* s = getenv("CRUCIBLE_LDS_TOP_KB")) h->lds_top_bytes = (size_t)std::max(0L, atol(s)) * 1024;
     if (const char* s = getenv("CRUCIBLE_BLOCKS_PER_CU")) h->blocks_per_cu_override = atoi(s);
     if (const char* s = getenv("CRUCIBLE_BLOCK")) h->block_override = atoi(s);
@@ -1026,7 +1085,7 @@ void cr_destroy(CrHandle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->s32.release(); h->s64.release();
     h->images.release(); h->texels.release(); h->work_counter.release(); h->counters.release();
-    h->att_stack.release(); h->out_buf.release();
+    h->att_stack.release(); h->out_buf.release(); h->sample_buf.release(); h->sg_acc.release();
     h->wf_job.release(); h->wf_rng.release(); h->wf_ray.release(); h->wf_depth.release(); h->wf_hit_t.release(); h->wf_hit_prim.release();
     h->wf_chunk.release(); h->wf_ctrl.release(); h->wf_samples.release(); h->wf_acc.release();
     if (h->wf_ring_host) { (void)hipHostFree(h->wf_ring_host); for (int i = 0; i < 8; i++) if (h->wf_ev[i]) (void)hipEventDestroy(h->wf_ev[i]); }

@@ -214,6 +214,14 @@ template <typename real> struct KernelArgs {
     int32_t output_sum;
     uint32_t tiles_x, tiles_y;
     uint32_t* work_counter;   // zeroed before launch
+    // Sample-granular scheduling (megakernel; speed only).  sg_on = 0: a lane owns a pixel and sums its samples
+    // in a register.  sg_on = 1: a work item is one (pixel, sample); 64 consecutive items are a tile of
+    // 2^sg_lw x 2^sg_lh pixels times 64 >> (sg_lw + sg_lh) consecutive samples, tiles_x/tiles_y count those tiles,
+    // sg_groups such groups cover a tile's samples [sample_begin, sample_end), and each finished sample's colour
+    // goes to sample_buf[((sample - sample_begin) * W*H + pixel) * 3] for sg_finalize_kernel to add in order.
+    uint32_t sg_on, sg_lw, sg_lh, sg_groups;
+    uint32_t sg_total;        // work items of the launch (tiles * sg_groups * 64)
+    real* sample_buf;
     uint64_t* counters;       // [0] segments [1] node tests [2] prim tests [3] texel fetches
     real* att_stack;          // 3 planes of max_depth * n_threads
     uint32_t n_threads;
@@ -718,8 +726,11 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t total_work = A.tiles_x * A.tiles_y * 64u;
+    const uint32_t total_work = A.sg_on ? A.sg_total : A.tiles_x * A.tiles_y * 64u;
     const CamConst<real>& cam = A.cam;
+    // sample-granular mode: the wave's private slice [wv_next, wv_end) of the work counter (same value in all lanes)
+    uint32_t wv_next = 0, wv_end = 0;
+    constexpr uint32_t SG_CHUNK = 1024;
 
     int state = ST_NEED_PIXEL;
     uint32_t pix_i = 0, pix_j = 0;
@@ -743,7 +754,37 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
         CR_DIAG_ONLY(d_iter++; d_t0 = __builtin_readcyclecounter();)
         // ---------------- regeneration: pixels
         uint64_t need = __ballot(state == ST_NEED_PIXEL);
-        if (need) {
+        if (need && A.sg_on) {
+            // One (pixel, sample) per lane.  The wave takes SG_CHUNK consecutive items from the global counter at a
+            // time and hands them to its lanes in order, so a wave stays on one tile's samples (coherent rays) and
+            // the counter sees one atomic per 1024 samples.
+            const uint32_t cnt = (uint32_t)__popcll(need), avail = wv_end - wv_next;
+            uint32_t fresh = 0;
+            if (cnt > avail) {
+                const int leader = __ffsll((unsigned long long)need) - 1;
+                if ((int)lane == leader) fresh = atomicAdd(A.work_counter, SG_CHUNK);
+                fresh = __shfl(fresh, leader);
+            }
+            if (state == ST_NEED_PIXEL) {
+                const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                // past the end of the counter's range (also when it wrapped): nothing left
+                const uint32_t w = rank < avail ? wv_next + rank : fresh + (rank - avail);
+                if (w >= total_work) state = ST_DONE;
+                else {
+                    const uint32_t group = w >> 6, in = w & 63u;
+                    const uint32_t tile = group / A.sg_groups, sg = group - tile * A.sg_groups;
+                    const uint32_t px = in & ((1u << A.sg_lw) - 1u), py = (in >> A.sg_lw) & ((1u << A.sg_lh) - 1u);
+                    const uint32_t ds = in >> (A.sg_lw + A.sg_lh);
+                    pix_i = ((tile % A.tiles_x) << A.sg_lw) + px;
+                    pix_j = ((tile / A.tiles_x) << A.sg_lh) + py;
+                    sample = A.sample_begin + (int32_t)(sg * (64u >> (A.sg_lw + A.sg_lh)) + ds);
+                    if (pix_i < (uint32_t)cam.W && pix_j < (uint32_t)cam.H && sample < A.sample_end) state = ST_NEED_SAMPLE;
+                    // else: padding of an edge tile or of the last sample group, ask again next round
+                }
+            }
+            if (cnt > avail) { wv_next = fresh + (cnt - avail); wv_end = fresh + SG_CHUNK; }
+            else wv_next += cnt;
+        } else if (need) {
             uint32_t cnt = (uint32_t)__popcll(need);
             uint32_t base = 0;
             int leader = __ffsll((unsigned long long)need) - 1;
@@ -809,7 +850,12 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
         }
 
         // ---------------- sample / pixel completion (average_samples, ray_casting.rs:154-173)
-        if (finished) {
+        if (finished && A.sg_on) {   // the ordered sum happens in sg_finalize_kernel
+            const size_t npix = (size_t)cam.W * (size_t)cam.H;
+            real* o = A.sample_buf + ((size_t)(sample - A.sample_begin) * npix + (size_t)pix_j * (size_t)cam.W + pix_i) * 3;
+            o[0] = col.x; o[1] = col.y; o[2] = col.z;
+            state = ST_NEED_PIXEL;
+        } else if (finished) {
             acc_r += col.x; acc_g += col.y; acc_b += col.z;
             sample++;
             if (sample == A.sample_end) {
@@ -849,6 +895,30 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
 
     }
 }
+// average_samples' running sum (ray_casting.rs:161-165) for the sample-granular mode: the batch's colours are added
+// to the pixel's sum in sample order, exactly the order the pixel-owning lane uses; the last batch divides by the
+// sample count (`/= count`, :168-170) or hands out the raw sum.
+template <typename real>
+__global__ void __launch_bounds__(256) sg_finalize_kernel(const KernelArgs<real> A, real* acc, int32_t batch_samples, int32_t first_batch,
+                                                          int32_t last_batch) {
+    const size_t npix = (size_t)A.cam.W * A.cam.H;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    real r = 0, g = 0, b = 0;
+    if (!first_batch) { r = acc[3 * p]; g = acc[3 * p + 1]; b = acc[3 * p + 2]; }
+    for (int32_t s = 0; s < batch_samples; s++) {
+        const real* c = A.sample_buf + ((size_t)s * npix + p) * 3;
+        r += c[0]; g += c[1]; b += c[2];
+    }
+    if (last_batch) {
+        if (A.output_sum) { A.out[3 * p] = r; A.out[3 * p + 1] = g; A.out[3 * p + 2] = b; }
+        else {
+            real cnt = (real)A.samples_total;
+            A.out[3 * p] = r / cnt; A.out[3 * p + 1] = g / cnt; A.out[3 * p + 2] = b / cnt;
+        }
+    } else { acc[3 * p] = r; acc[3 * p + 1] = g; acc[3 * p + 2] = b; }
+}
+
 #endif   // __HIPCC__
 
 }   // namespace cr

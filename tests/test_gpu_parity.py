@@ -219,14 +219,18 @@ def test_teapot_with_environment_map(renderer, oracles, rt, tag):
 @pytest.mark.parametrize("env", [{"CRUCIBLE_PIPELINE": "wavefront"}, {"CRUCIBLE_PIPELINE": "wavefront", "CRUCIBLE_WF_SLOTS": "4096", "CRUCIBLE_WF_SAMPLE_MB": "1"},
                                  {"CRUCIBLE_WALK_EXIT": "24"}, {"CRUCIBLE_BLOCK": "256"}, {"CRUCIBLE_PIPELINE": "queue"},
                                  {"CRUCIBLE_PIPELINE": "queue", "CRUCIBLE_QUEUE_WALKERS": "3", "CRUCIBLE_QUEUE_BATCH": "1"},
-                                 {"CRUCIBLE_PIPELINE": "queue", "CRUCIBLE_QUEUE_WALKERS": "15", "CRUCIBLE_WALK_ROUND": "2"}],
+                                 {"CRUCIBLE_PIPELINE": "queue", "CRUCIBLE_QUEUE_WALKERS": "15", "CRUCIBLE_WALK_ROUND": "2"},
+                                 {"CRUCIBLE_SAMPLE_GRANULAR": "0"}, {"CRUCIBLE_SAMPLE_BUF_MB": "0"}, {"CRUCIBLE_SG_TILE": "8x8"},
+                                 {"CRUCIBLE_SG_TILE": "2x2"}, {"CRUCIBLE_SG_TILE": "1x1", "CRUCIBLE_BLOCK": "512"}],
                          ids=["wavefront", "wavefront-small-batches", "walk-exit-24", "block-256", "queue", "queue-3-walkers",
-                              "queue-15-walkers"])
+                              "queue-15-walkers", "pixel-granular", "one-sample-batches", "sg-tile-8x8", "sg-tile-2x2", "sg-tile-1x1"])
 def test_alternative_schedules_are_bit_identical(oracles, monkeypatch, rt, tag, env):
     """The wavefront pipeline (logic / extend / finalize kernels over SoA path state, also with tiny slot counts
     and many sample batches), the LDS-queue megakernel (walker and shader waves exchanging path slots through
-    LDS rings, at several splits), an early walk exit and another workgroup size only change WHEN a path's
-    operations run, never which: images and counters stay bit-equal to the oracle."""
+    LDS rings, at several splits), an early walk exit, another workgroup size, and the megakernel's work scheduling
+    (a lane owning a pixel vs. the default sample-granular hand-out with its per-sample colour buffer, in one batch or
+    in batches of a single sample, at several tile shapes) only change WHEN a path's operations run, never which:
+    images and counters stay bit-equal to the oracle."""
     from crucible_amd.renderer import Renderer
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -417,3 +421,28 @@ def test_error_codes(renderer, hiplib):
         renderer.upload_scene(flat)
     h = C.c_void_p()
     assert hiplib.cr_create(10 ** 6, C.byref(h)) == A.CR_ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+def test_sample_batches_keep_the_sequential_sum(oracles, monkeypatch, rt, tag):
+    """A colour buffer too small for all samples: the render runs in batches of 2-3 samples per pixel and
+    sg_finalize_kernel carries the running sums between them -- still average_samples' order (ray_casting.rs:154-173),
+    also for a shard of the sample range returned as raw sums."""
+    from crucible_amd.renderer import Renderer
+    monkeypatch.setenv("CRUCIBLE_SAMPLE_BUF_MB", "8")     # 640x360: 2.8 MB (f32) / 5.5 MB (f64) per sample index
+    r = Renderer(0)
+    try:
+        sc = book1_end_scene(1, scene_seed=4, image_width=640, samples=7)
+        img, st = gpu_render(r, sc, rt)
+        ref, rst = oracles[rt].render_image(sc, seed=SEED)
+        assert_exact(img, st, ref, rst)
+        a, _ = r.render(sc.scene_cam, seed=SEED, real_type=rt, sample_begin=1, sample_count=5, output_sum=True)
+        o = oracles[rt]
+        h = o.scene_create(sc.flatten())
+        try:
+            b, _ = o.render(h, sc.scene_cam, seed=SEED, sample_begin=1, sample_count=5, output_sum=True)
+        finally:
+            o.scene_destroy(h)
+        assert np.array_equal(a.reshape(-1, 3), b)
+    finally:
+        r.close()
