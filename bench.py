@@ -190,7 +190,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = f"{args.workload}_{W}x{H}_spp{s_count}_{args.real}"
+                key = f"{args.workload}_{W}x{H}_spp{s_count}_{args.real}" + ("" if args.bvh == "reference" else "_" + args.bvh)
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -198,7 +198,8 @@ def main():
         vpath = os.path.join(ROOT, "profiles", "valu.json")
         if os.path.exists(vpath):
             try:
-                valu = json.load(open(vpath)).get(f"{args.workload}_{W}x{H}_spp{s_count}_{args.real}")
+                valu = json.load(open(vpath)).get(f"{args.workload}_{W}x{H}_spp{s_count}_{args.real}" +
+                                                  ("" if args.bvh == "reference" else "_" + args.bvh))
             except Exception:
                 valu = None
         try:
@@ -220,7 +221,8 @@ def main():
                                                                      f"spp-shard x{world} + {args.backend} reduce of the RGB sums")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "cr::pathtrace_kernel", "kernel_ms": round(k_ms, 4),
+                         "kernel": "cr::pathtrace_kernel (kernel_ms also covers the ~2 ms ordered-sum kernel cr::sg_finalize_kernel)",
+                         "kernel_ms": round(k_ms, 4),
                          "algorithmic_bytes_per_launch": int(B),
                          "counters_per_launch": {k: st[k] for k in ("samples", "segments", "node_tests", "prim_tests",
                                                                     "texel_fetches")}},
