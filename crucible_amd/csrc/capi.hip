@@ -20,6 +20,7 @@
 #include <map>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 #include <zlib.h>
 
@@ -98,6 +99,10 @@ struct CrHandle {
     int sample_granular = 1;             // CRUCIBLE_SAMPLE_GRANULAR=0: a lane owns a pixel (no buffer)
     size_t sample_buf_limit = (size_t)16 << 30;   // CRUCIBLE_SAMPLE_BUF_MB
     int sg_lw = -1, sg_lh = -1;          // CRUCIBLE_SG_TILE=WxH (powers of two, W*H <= 64); default 4x4 pixels x 4 samples
+    // f32 trees with more than latency_entries wrappers run on pathtrace_kernel_latency (6 waves/SIMD) with a
+    // latency_top_bytes LDS window, three 512-thread groups per CU.  CRUCIBLE_LATENCY_ENTRIES (0 = never).
+    int32_t latency_entries = 65536;
+    size_t latency_top_bytes = 48 * 1024;
     size_t lds_top_bytes = 64 * 1024;   // LDS spent on the top of a tree that does not fit whole (CRUCIBLE_LDS_TOP_KB; 0 = none)
     int blocks_per_cu_override = 0;
     int block_override = 0;
@@ -536,18 +541,21 @@ template <typename real> void key_to_real(const CrKeyframe& k, Key<real>& o) {
     o.t0 = (real)k.t0; o.t1 = (real)k.t1; o.a = (real)k.a; o.b = (real)k.b; o.channel = k.channel; o.interp = k.interp;
 }
 
-template <typename real, int RES, bool ANIM, bool ORD = false>
+template <typename real, int RES, bool ANIM, bool ORD = false, bool LATENCY = false>
 int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, CrStats* stats) {
     constexpr bool LDS = RES != RES_GLOBAL;
+    static_assert(!LATENCY || RES == RES_TOP, "the 6-waves-per-SIMD entry point exists for RES_TOP only");
     KernelArgs<real> args = args_in;
-    auto kern = pathtrace_kernel<real, RES, ANIM, ORD>;
+    void (*kern)(const KernelArgs<real>) = pathtrace_kernel<real, RES, ANIM, ORD>;
+    if (LATENCY) kern = pathtrace_kernel_latency<real, ANIM, ORD>;
+    const int max_block = LATENCY ? LatencyBlock : MaxBlock<real>::value;
     if (LDS) HIP_TRY(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     // Workgroup size: the candidate that keeps the most waves resident per CU (a larger
     // workgroup shares one LDS copy of the scene among more waves); ties go to the larger.
     int block = 256, per_cu = 1, best_waves = 0;
     for (int cand : {1024, 512, 256}) {
-        if (cand > MaxBlock<real>::value) continue;
-        if (h->block_override > 0 && cand != h->block_override) continue;
+        if (cand > max_block) continue;
+        if (h->block_override > 0 && cand != h->block_override && h->block_override <= max_block) continue;
         int n = 0;
         HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, cand, LDS ? lds_bytes : 0));
         if (n * cand / 64 > best_waves) { best_waves = n * cand / 64; block = cand; per_cu = n; }
@@ -919,10 +927,13 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
             a.lds_entries = ds.n_entries;
             return anim ? launch<real, RES_LDS, true, true>(h, a, ds.lds_bytes, stats) : launch<real, RES_LDS, false, true>(h, a, ds.lds_bytes, stats);
         }
-        const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, h->lds_top_bytes / sizeof(EntryO<real>));
+        constexpr bool f32 = std::is_same<real, float>::value;   // the double kernel needs far more than 80 VGPRs: it halves there
+        const bool latency = f32 && h->latency_entries > 0 && ds.n_entries > h->latency_entries;
+        const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, (latency ? h->latency_top_bytes : h->lds_top_bytes) / sizeof(EntryO<real>));
         if (top > 0) {
             a.lds_entries = top;
             const size_t bytes = (size_t)top * sizeof(EntryO<real>);
+            if constexpr (f32) if (latency) return anim ? launch<real, RES_TOP, true, true, true>(h, a, bytes, stats) : launch<real, RES_TOP, false, true, true>(h, a, bytes, stats);
             return anim ? launch<real, RES_TOP, true, true>(h, a, bytes, stats) : launch<real, RES_TOP, false, true>(h, a, bytes, stats);
         }
         a.lds_entries = 0;
@@ -946,10 +957,13 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
         a.lds_entries = ds.n_entries;
         return anim ? launch<real, RES_LDS, true>(h, a, ds.lds_bytes, stats) : launch<real, RES_LDS, false>(h, a, ds.lds_bytes, stats);
     }
-    const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, h->lds_top_bytes / sizeof(Entry<real>));
+    constexpr bool f32 = std::is_same<real, float>::value;   // the double kernel needs far more than 80 VGPRs: it halves there
+    const bool latency = f32 && h->latency_entries > 0 && ds.n_entries > h->latency_entries;
+    const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, (latency ? h->latency_top_bytes : h->lds_top_bytes) / sizeof(Entry<real>));
     if (top > 0) {   // large scene: the top levels of the tree in LDS, everything else through L2
         a.lds_entries = top;
         const size_t bytes = (size_t)top * sizeof(Entry<real>);
+        if constexpr (f32) if (latency) return anim ? launch<real, RES_TOP, true, false, true>(h, a, bytes, stats) : launch<real, RES_TOP, false, false, true>(h, a, bytes, stats);
         return anim ? launch<real, RES_TOP, true>(h, a, bytes, stats) : launch<real, RES_TOP, false>(h, a, bytes, stats);
     }
     a.lds_entries = 0;
@@ -1064,6 +1078,7 @@ int32_t cr_create(int32_t device_id, CrHandle** out) {
             h->sg_lw = __builtin_ctz((unsigned)tw); h->sg_lh = __builtin_ctz((unsigned)th);
         }
     }
+    if (const char* s = getenv("CRUCIBLE_LATENCY_ENTRIES")) h->latency_entries = (int32_t)std::max(0L, atol(s));
     if (const char* s = getenv("CRUCIBLE_LDS_TOP_KB")) h->lds_top_bytes = (size_t)std::max(0L, atol(s)) * 1024;
     if (const char* s = getenv("CRUCIBLE_BLOCKS_PER_CU")) h->blocks_per_cu_override = atoi(s);
     if (const char* s = getenv("CRUCIBLE_BLOCK")) h->block_override = atoi(s);

@@ -694,8 +694,8 @@ template <typename real> struct MaxBlock { static constexpr int value = 1024; };
 // One lane = one pixel at a time, all of that pixel's samples in draw order (so the
 // per-pixel sum is the reference's sequential sum).  Lanes that finish a pixel pull the
 // next pixel index with one wave-aggregated atomic (ballot + prefix count).
-template <typename real, int RES, bool ANIM, bool ORD = false>
-__global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const KernelArgs<real> A) {
+template <typename real, int RES, bool ANIM, bool ORD>
+CR_D void pathtrace_body(const KernelArgs<real>& A) {
     using EntryT = typename EntryOf<real, ORD>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Entry<real>* lds_entries = nullptr;
@@ -895,6 +895,22 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
 
     }
 }
+template <typename real, int RES, bool ANIM, bool ORD = false>
+__global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const KernelArgs<real> A) {
+    pathtrace_body<real, RES, ANIM, ORD>(A);
+}
+
+// The same kernel compiled for 6 waves per SIMD (<= 80 VGPRs, 512-thread groups), for trees far larger than the
+// LDS window: there the walk waits on L2 / HBM reads and more resident waves hide more of that latency than the
+// extra spills cost (1M spheres +11 %; the LDS-resident book1 and the 8K-wrapper teapot lose 3 % and stay on
+// pathtrace_kernel).  RES_TOP only.
+constexpr int LatencyBlock = 512;
+template <typename real, bool ANIM, bool ORD = false>
+__global__ void __attribute__((amdgpu_flat_work_group_size(64, LatencyBlock), amdgpu_waves_per_eu(6, 6)))
+pathtrace_kernel_latency(const KernelArgs<real> A) {
+    pathtrace_body<real, RES_TOP, ANIM, ORD>(A);
+}
+
 // average_samples' running sum (ray_casting.rs:161-165) for the sample-granular mode: the batch's colours are added
 // to the pixel's sum in sample order, exactly the order the pixel-owning lane uses; the last batch divides by the
 // sample count (`/= count`, :168-170) or hands out the raw sum.

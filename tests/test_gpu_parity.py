@@ -221,15 +221,18 @@ def test_teapot_with_environment_map(renderer, oracles, rt, tag):
                                  {"CRUCIBLE_PIPELINE": "queue", "CRUCIBLE_QUEUE_WALKERS": "3", "CRUCIBLE_QUEUE_BATCH": "1"},
                                  {"CRUCIBLE_PIPELINE": "queue", "CRUCIBLE_QUEUE_WALKERS": "15", "CRUCIBLE_WALK_ROUND": "2"},
                                  {"CRUCIBLE_SAMPLE_GRANULAR": "0"}, {"CRUCIBLE_SAMPLE_BUF_MB": "0"}, {"CRUCIBLE_SG_TILE": "8x8"},
-                                 {"CRUCIBLE_SG_TILE": "2x2"}, {"CRUCIBLE_SG_TILE": "1x1", "CRUCIBLE_BLOCK": "512"}],
+                                 {"CRUCIBLE_SG_TILE": "2x2"}, {"CRUCIBLE_SG_TILE": "1x1", "CRUCIBLE_BLOCK": "512"},
+                                 {"CRUCIBLE_LATENCY_ENTRIES": "1", "CRUCIBLE_LDS_LIMIT": "4096"}],
                          ids=["wavefront", "wavefront-small-batches", "walk-exit-24", "block-256", "queue", "queue-3-walkers",
-                              "queue-15-walkers", "pixel-granular", "one-sample-batches", "sg-tile-8x8", "sg-tile-2x2", "sg-tile-1x1"])
+                              "queue-15-walkers", "pixel-granular", "one-sample-batches", "sg-tile-8x8", "sg-tile-2x2", "sg-tile-1x1",
+                              "six-waves-per-simd-entry-point"])
 def test_alternative_schedules_are_bit_identical(oracles, monkeypatch, rt, tag, env):
     """The wavefront pipeline (logic / extend / finalize kernels over SoA path state, also with tiny slot counts
     and many sample batches), the LDS-queue megakernel (walker and shader waves exchanging path slots through
     LDS rings, at several splits), an early walk exit, another workgroup size, and the megakernel's work scheduling
     (a lane owning a pixel vs. the default sample-granular hand-out with its per-sample colour buffer, in one batch or
-    in batches of a single sample, at several tile shapes) only change WHEN a path's operations run, never which:
+    in batches of a single sample, at several tile shapes), and the 6-waves-per-SIMD entry point used for very large
+    trees (forced here onto small ones; f32 only, f64 stays on the regular kernel) only change WHEN a path's operations run, never which:
     images and counters stay bit-equal to the oracle."""
     from crucible_amd.renderer import Renderer
     for k, v in env.items():
