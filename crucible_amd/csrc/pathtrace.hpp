@@ -319,6 +319,20 @@ CR_D bool box_hit_fast(const real* b, Pair<real> ox, Pair<real> oy, Pair<real> o
     real hi = r_min(r_min(r_max(tx.x, tx.y), r_max(ty.x, ty.y)), r_min(r_max(tz.x, tz.y), tmax));
     return !(hi <= lo);
 }
+// The complement, for callers that combine it with other masks: Aabb::hit's `max <= min -> miss`.
+// min(h, tmax) <= lo is evaluated as h <= lo || tmax <= lo: identical for every input the fast path sees (the slab
+// distances are never NaN there, and a NaN tmax is ignored by either form), and one instruction shorter because
+// v_min would first have to canonicalise tmax.
+template <typename real>
+CR_D bool box_miss_fast(const real* b, Pair<real> ox, Pair<real> oy, Pair<real> oz, Pair<real> ix, Pair<real> iy, Pair<real> iz,
+                        real tmin, real tmax) {
+    Pair<real> tx = (Pair<real>{b[0], b[1]} - ox) * ix;
+    Pair<real> ty = (Pair<real>{b[2], b[3]} - oy) * iy;
+    Pair<real> tz = (Pair<real>{b[4], b[5]} - oz) * iz;
+    real lo = r_max(r_max(r_min(tx.x, tx.y), r_min(ty.x, ty.y)), r_max(r_min(tz.x, tz.y), tmin));
+    real hi = r_min(r_min(r_max(tx.x, tx.y), r_max(ty.x, ty.y)), r_max(tz.x, tz.y));
+    return (hi <= lo) | (tmax <= lo);
+}
 
 // Sphere::hit root search (sphere.rs:72-95): returns t or a negative number for a miss.
 template <typename real>
@@ -627,15 +641,20 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
         if (!w.exact_box) {
             const Pair<real> ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
             const Pair<real> ix = {w.inv.x, w.inv.x}, iy = {w.inv.y, w.inv.y}, iz = {w.inv.z, w.inv.z};
-            while (w.idx < n_entries) {
+            // `it` is the same in every lane still in the loop (a scalar register); tmax cannot change inside it
+            const real tmax = w.best_t;
+            uint32_t nodes = 0;
+            for (uint32_t it = 0; w.idx < n_entries; it++) {
                 const Entry<real> e = ORD ? fetch_entry_ordered<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx, w.oct)
                                           : fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx);
-                c_node++;
-                bool hit = box_hit_fast(e.b, ox, oy, oz, ix, iy, iz, tmin, w.best_t);
-                w.idx = (hit && e.leaf < 0) ? (ORD ? ordered_near(e.leaf, w.oct) : -e.leaf) : e.skip;
-                if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
-                if (--budget == 0) break;
+                nodes++;
+                const bool miss = box_miss_fast(e.b, ox, oy, oz, ix, iy, iz, tmin, tmax);
+                const bool inner = e.leaf < 0;
+                w.idx = (inner && !miss) ? (ORD ? ordered_near(e.leaf, w.oct) : -e.leaf) : e.skip;
+                if (!(miss || inner)) { leaf = e.leaf; break; }
+                if (it + 1 == budget) break;
             }
+            c_node += nodes;
         } else {
             while (w.idx < n_entries) {
                 const Entry<real> e = ORD ? fetch_entry_ordered<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx, w.oct)
