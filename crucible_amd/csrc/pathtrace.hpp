@@ -95,7 +95,11 @@ template <typename real> CR_HD V3<real> c_div(V3<real> c, real s) {
 }
 
 // ------------------------------------------------------------------ RNG (DESIGN.md "RNG")
-// Counter-based SplitMix64: draw n of (seed, pixel, sample) = mix64(key + (n+1)*GAMMA).
+// One stream per (seed, pixel, sample): the key is SplitMix64's finaliser of those three (mix64), the draws are
+// xorshift64* (Marsaglia's 12/25/27 xorshift scrambled by one multiply; Vigna, "An experimental exploration of
+// Marsaglia's xorshift generators, scrambled", 2016) started from that key.  One 64-bit multiply per draw instead
+// of SplitMix64's two -- 64-bit multiplies are quarter-rate here and the draws were ~10 % of the kernel.  Only the
+// top 24 (f32) / 53 (f64) bits of an output are used, so f32 uniforms are truncations of the f64 ones.
 constexpr uint64_t RNG_GAMMA = 0x9E3779B97F4A7C15ULL;
 CR_HD uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -103,7 +107,12 @@ CR_HD uint64_t mix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 CR_HD uint64_t rng_key(uint64_t seed_mixed, uint32_t pixel, uint32_t sample) {
-    return mix64(seed_mixed ^ (((uint64_t)pixel << 32) | (uint64_t)sample));
+    const uint64_t k = mix64(seed_mixed ^ (((uint64_t)pixel << 32) | (uint64_t)sample));
+    return k ? k : RNG_GAMMA;   // xorshift state must not be zero
+}
+CR_HD uint64_t rng_next(uint64_t& s) {
+    s ^= s >> 12; s ^= s << 25; s ^= s >> 27;
+    return s * 0x2545F4914F6CDD1DULL;
 }
 // The conversions go through 32-bit words (exact: 24 resp. 21+32 significant bits), which is much
 // cheaper on the GPU than the generic u64 -> float sequence and yields the same value.
@@ -112,7 +121,7 @@ CR_HD double u01(uint64_t u, double) {
     const uint64_t v = u >> 11;
     return ((double)(uint32_t)(v >> 32) * 4294967296.0 + (double)(uint32_t)v) * 0x1.0p-53;
 }
-template <typename real> CR_HD real rng_uniform(uint64_t& s) { s += RNG_GAMMA; return u01(mix64(s), real(0)); }
+template <typename real> CR_HD real rng_uniform(uint64_t& s) { return u01(rng_next(s), real(0)); }
 template <typename real> CR_HD real rng_range(uint64_t& s, real lo, real hi) { return lo + (hi - lo) * rng_uniform<real>(s); }
 
 template <typename real> CR_HD V3<real> random_unit_vector(uint64_t& s) {   // utils.rs:127-136

@@ -201,8 +201,8 @@ typedef struct CrCameraDesc {
  * Per-render parameters.  samples/max_depth/frame/frame_rate/shutter_angle are
  * Camera fields (camera/mod.rs:83-99).  The reference draws every random number
  * from an unseeded thread-local generator (rand::rng(), ray_casting.rs:74); this
- * ABI replaces it with a counter-based generator keyed by
- * (seed, pixel index, sample index, draw index) -- see DESIGN.md "RNG".
+ * ABI replaces it with one seeded stream per (seed, pixel index, sample index)
+ * (SplitMix64-derived key, xorshift64* draws) -- see DESIGN.md "RNG".
  * sample_begin/sample_count select a sub-range of the `samples` sample indices
  * (samples-per-pixel sharding across GPUs); the mean is still taken over
  * `samples` when the sums of all shards are added.

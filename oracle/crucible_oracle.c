@@ -33,8 +33,9 @@
  *
  * Deliberate, documented departures from the reference:
  *  - RNG: rand::rng() (thread-local ChaCha12, OS-seeded; rand 0.9.2, not vendored)
- *    is replaced by a counter-based SplitMix64 stream keyed by
- *    (seed, pixel index, sample index); draw n is mix64(key + (n+1)*GAMMA).
+ *    is replaced by one seeded stream per (seed, pixel index, sample index):
+ *    key = SplitMix64's finaliser of the three, draws = xorshift64* (Vigna 2016)
+ *    started from that key.
  *    uniform [0,1): f64 = (u>>11)*2^-53 (rand's StandardUniform mapping),
  *    f32 = (u>>40)*2^-24; random_range(lo..hi) and (lo..=hi) = lo + (hi-lo)*u.
  *  - powi(2) = x*x; powi(5) = x*((x*x)*(x*x)) (LLVM's expansion of llvm.powi).
@@ -185,10 +186,17 @@ typedef struct { uint64_t s; uint64_t draws; } Rng;
 static Rng rng_for_sample(uint64_t seed, uint32_t pixel, uint32_t sample) {
     Rng r;
     r.s = mix64(mix64(seed + RNG_GAMMA) ^ (((uint64_t)pixel << 32) | (uint64_t)sample));
+    if (r.s == 0) r.s = RNG_GAMMA;   /* xorshift state must not be zero */
     r.draws = 0;
     return r;
 }
-static uint64_t rng_u64(Rng* r) { r->s += RNG_GAMMA; r->draws++; return mix64(r->s); }
+/* xorshift64* (Vigna 2016): Marsaglia's 12/25/27 xorshift, output scrambled by one multiply */
+static uint64_t rng_u64(Rng* r) {
+    uint64_t s = r->s;
+    s ^= s >> 12; s ^= s << 25; s ^= s >> 27;
+    r->s = s; r->draws++;
+    return s * 0x2545F4914F6CDD1DULL;
+}
 static real rng_uniform(Rng* r) {
     uint64_t u = rng_u64(r);
 #if defined(CR_ORACLE_F32)

@@ -275,3 +275,30 @@ def test_refit_boxes_identity_without_motion(o64):
     sc.scene_cam.refit_boxes = True
     b, sb = o64.render_image(sc, seed=9)
     assert np.array_equal(a, b) and sa["node_tests"] == sb["node_tests"]
+
+
+def test_rng_streams_look_uniform_and_independent(o64):
+    """One xorshift64* stream per (seed, pixel, sample), keyed by SplitMix64's finaliser: first draws of neighbouring
+    keys must be uniform and uncorrelated (a weak key derivation would show up exactly here: the scheduler hands
+    neighbouring pixels and consecutive samples to neighbouring lanes)."""
+    n_pix, n_smp, n_draw = 64, 64, 6
+    u = np.zeros((n_pix, n_smp, n_draw))
+    buf = np.zeros(n_draw)
+    for p in range(n_pix):
+        for s in range(n_smp):
+            o64.lib.oracle_rng_uniforms(1234, p, s, n_draw, buf.ctypes.data)
+            u[p, s] = buf
+    n = u.size
+    assert abs(u.mean() - 0.5) < 4 * np.sqrt(1 / 12 / n)
+    assert abs(u.var() - 1 / 12) < 0.002
+    assert 0.0 <= u.min() and u.max() < 1.0
+    hist = np.histogram(u, bins=16, range=(0, 1))[0]
+    assert ((hist - n / 16) ** 2 / (n / 16)).sum() < 45          # chi-square, 15 dof: p ~ 1e-4
+    c = lambda a, b: abs(np.corrcoef(a.ravel(), b.ravel())[0, 1])
+    lim = 5 / np.sqrt(n_pix * n_smp)
+    assert c(u[:, :-1, 0], u[:, 1:, 0]) < lim        # consecutive samples of a pixel
+    assert c(u[:-1, :, 0], u[1:, :, 0]) < lim        # neighbouring pixels
+    assert c(u[:, :, 0], u[:, :, 1]) < lim and c(u[:, :, 1], u[:, :, 2]) < lim   # consecutive draws of a stream
+    # a different seed gives a different stream
+    o64.lib.oracle_rng_uniforms(1235, 0, 0, n_draw, buf.ctypes.data)
+    assert not np.array_equal(buf, u[0, 0])
