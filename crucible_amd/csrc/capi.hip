@@ -106,7 +106,7 @@ struct CrHandle {
     size_t lds_top_bytes = 64 * 1024;   // LDS spent on the top of a tree that does not fit whole (CRUCIBLE_LDS_TOP_KB; 0 = none)
     int blocks_per_cu_override = 0;
     int block_override = 0;
-    int walk_round_steps = 12;         // 0 = a round lasts until every walking lane found a leaf or ran out (measured: 12)
+    int walk_round_steps = 10;         // 0 = a round lasts until every walking lane found a leaf or ran out (measured: 10)
     int walk_exit_lanes = 56;          // leave the walk phase once this many lanes are not walking (64 = wait for all; measured: 56)
     int last_block = 0, last_grid = 0;
     bool check_abort = false;          // the last launch was a queue kernel whose abort word has not been read yet
