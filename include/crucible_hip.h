@@ -257,15 +257,20 @@ CR_API int32_t cr_create(int32_t device_id, CrHandle** out);
 CR_API void cr_destroy(CrHandle* h);
 
 /* Copies the whole description (the caller may free it on return), filters
- * hidden primitives and builds the BVH in reference topology
- * (BVHWrapper::new_wrapper, src/objects/bvhwrapper.rs:15-93) for both scalar types
- * lazily.  Replaces the `world`/`skybox` arguments of Camera::render. */
+ * hidden primitives and builds the BVH selected by scene->bvh_mode -- by default the
+ * reference topology (BVHWrapper::new_wrapper, src/objects/bvhwrapper.rs:15-93) -- for
+ * each scalar type on first use.  Replaces the `world`/`skybox` arguments of Camera::render. */
 CR_API int32_t cr_upload_scene(CrHandle* h, const CrSceneDesc* scene);
 
 /* Camera::render minus the file output: renders into a DEVICE buffer of
  * image_width*image_height*3 reals (f32 or f64 per params->real_type), row-major,
  * RGB interleaved.  Asynchronous on the handle's stream unless `stats` is non-NULL
- * (then it synchronises to fill the stats). */
+ * (then it synchronises to fill the stats).
+ * Device memory: besides the scene the handle keeps a per-path attenuation stack (3*max_depth reals per
+ * resident lane, ~150 MB at depth 50) and a per-sample colour buffer of image_width*image_height*3 reals per
+ * sample index, up to 16 GiB (CRUCIBLE_SAMPLE_BUF_MB; a render that needs more runs as consecutive sample
+ * batches, CRUCIBLE_SAMPLE_GRANULAR=0 avoids the buffer at a large cost in speed).  The buffers are
+ * grown on demand, reused by later renders and freed by cr_destroy. */
 CR_API int32_t cr_render_device(CrHandle* h, const CrCameraDesc* cam, const CrRenderParams* params,
                          void* d_out_rgb, CrStats* stats);
 
