@@ -449,3 +449,30 @@ def test_sample_batches_keep_the_sequential_sum(oracles, monkeypatch, rt, tag):
         assert np.array_equal(a.reshape(-1, 3), b)
     finally:
         r.close()
+
+
+def test_headline_config_at_full_sample_count(renderer, oracles):
+    """BASELINE config 2 exactly as benchmarked (book1 1920x1080 @ 512 spp, depth 50, f32): two renders identical,
+    two rows bit-for-bit against the oracle at all 512 samples (the sequential per-pixel sum through 512 terms),
+    and eight 64-sample shards add up to the frame within f32 re-association error (the multi-GPU split)."""
+    sc = book1_end_scene(1, scene_seed=1, image_width=1920, samples=512)
+    cam = sc.scene_cam
+    renderer.upload_scene(sc.flatten())
+    img, st = renderer.render(cam, seed=SEED, real_type=A.CR_REAL_F32)
+    again, st2 = renderer.render(cam, seed=SEED, real_type=A.CR_REAL_F32)
+    assert st["samples"] == 1920 * 1080 * 512 and st["nan_pixels"] == 0
+    assert np.array_equal(img, again) and all(st[k] == st2[k] for k in COUNTERS)
+    assert img.min() >= 0.0 and img.max() <= 1.0
+    o = oracles[A.CR_REAL_F32]
+    h = o.scene_create(sc.flatten())
+    try:
+        for row in (97, 803):
+            ref, _ = o.render(h, cam, seed=SEED, pix_begin=row * 1920, pix_end=(row + 1) * 1920)
+            assert np.array_equal(img[row], ref), row
+    finally:
+        o.scene_destroy(h)
+    total = np.zeros(img.shape, dtype=np.float64)
+    for k in range(8):
+        part, _ = renderer.render(cam, seed=SEED, real_type=A.CR_REAL_F32, sample_begin=64 * k, sample_count=64, output_sum=True)
+        total += part
+    assert np.abs(total / 512.0 - img).max() < 2e-5
