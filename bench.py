@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["book1", "teapot", "million", "movie"], default="book1",
                     help="book1 = BASELINE configs[1] (the headline); teapot/million/movie = configs[2]/[3]/[4], extra lines")
-    ap.add_argument("--bvh", choices=["reference", "sah", "ordered"], default="reference",
+    ap.add_argument("--bvh", choices=["reference", "sah", "ordered", "lbvh"], default="reference",
                     help="reference = the reference's median-split tree (parity mode, the headline); sah = the quality "
                          "builder of SURVEY 8(f) row 1 (same walk, other topology); ordered = that tree walked near child first. "
                          "Both are extra lines, not the headline")
@@ -124,7 +124,7 @@ def main():
         wl = "teapot orbit movie (240 frames at 24 fps), one frame per rank per step, {W}x{H} @ {spp} spp, depth {d} -- configs[4]"
         prim_bytes = 36 if args.real == "f32" else 72
         frame_sharded = True
-    scene.bvh_mode = {"sah": A.CR_BVH_SAH, "ordered": A.CR_BVH_SAH_ORDERED}.get(args.bvh, A.CR_BVH_REFERENCE)
+    scene.bvh_mode = {"sah": A.CR_BVH_SAH, "ordered": A.CR_BVH_SAH_ORDERED, "lbvh": A.CR_BVH_LBVH}.get(args.bvh, A.CR_BVH_REFERENCE)
     cam = scene.scene_cam
     W, H, spp = cam.image_width, cam.image_height, cam.samples
     if frame_sharded:
@@ -214,8 +214,9 @@ def main():
                        "image": [W, H], "spp": spp, "max_depth": cam.max_depth, "scene_seed": scene_seed, "rng_seed": seed,
                        "primitives": len(scene.elements), "bvh_entries": st["bvh_entries"],
                        "bvh": "reference topology (median split, bvhwrapper.rs:46-78)" if args.bvh == "reference" else
-                              ("binned SAH topology (CR_BVH_SAH; not the reference's tree)" if args.bvh == "sah" else
-                               "binned SAH topology walked near child first (CR_BVH_SAH_ORDERED; not the reference's tree or order)"),
+                              {"sah": "binned SAH topology (CR_BVH_SAH; not the reference's tree)",
+                               "ordered": "binned SAH topology walked near child first (CR_BVH_SAH_ORDERED; not the reference's tree or order)",
+                               "lbvh": "Morton-code LBVH built on the device (CR_BVH_LBVH; not the reference's tree)"}[args.bvh],
                        "scene_residency": {0: "L2", 1: "whole scene in LDS", 2: "BVH top levels in LDS"}.get(st["scene_in_lds"]),
                        "parallelism": "1 GPU" if world == 1 else (f"frame-shard x{world}, no collective" if frame_sharded else
                                                                      f"spp-shard x{world} + {args.backend} reduce of the RGB sums")},

@@ -10,7 +10,7 @@ CR_PRIM_HIDDEN = 1
 CR_MAT_LAMBERTIAN, CR_MAT_METAL, CR_MAT_DIELECTRIC = 0, 1, 2
 CR_TEX_SOLID, CR_TEX_CHECKER, CR_TEX_IMAGE = 0, 1, 2
 CR_SKY_DEFAULT, CR_SKY_SPHERICAL = 0, 1
-CR_BVH_REFERENCE, CR_BVH_SAH, CR_BVH_SAH_ORDERED = 0, 1, 2
+CR_BVH_REFERENCE, CR_BVH_SAH, CR_BVH_SAH_ORDERED, CR_BVH_LBVH = 0, 1, 2, 3
 CR_KEY_TX, CR_KEY_TY, CR_KEY_TZ, CR_KEY_RADIUS = 0, 1, 2, 3
 CR_KEY_NERP, CR_KEY_LERP = 0, 1
 

@@ -9,6 +9,8 @@
 #include "wavefront.hpp"
 #include "queue.hpp"
 #include "refit.hpp"
+#include "lbvh.hpp"
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <atomic>
@@ -387,10 +389,112 @@ template <typename real> struct SahBuilder {
     }
 };
 
+// Boxes of every wrapper of `entries` (a device copy of the tree), bottom-up by level: for the ray times [ta, tb]
+// of a frame (use_keys) or the construction-time boxes (!use_keys).
+template <typename real>
+int32_t run_box_kernels(CrHandle* h, DevScene<real>& ds, void* entries, real ta, real tb, bool use_keys) {
+    for (size_t l = ds.level_begin.size() - 1; l-- > 0;) {
+        const int32_t begin = ds.level_begin[l], end = ds.level_begin[l + 1];
+        if (end <= begin) continue;
+        const dim3 grid((unsigned)((end - begin + 255) / 256)), block(256);
+        if (ds.ordered) hipLaunchKernelGGL((refit_level_kernel<real, true>), grid, block, 0, h->stream, (EntryO<real>*)entries, begin, end,
+                                           (const Prim<real>*)ds.prims.p, (const Key<real>*)ds.keys.p, ta, tb, use_keys ? 1 : 0);
+        else hipLaunchKernelGGL((refit_level_kernel<real, false>), grid, block, 0, h->stream, (Entry<real>*)entries, begin, end,
+                                (const Prim<real>*)ds.prims.p, (const Key<real>*)ds.keys.p, ta, tb, use_keys ? 1 : 0);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return CR_OK;
+}
+
+// CR_BVH_LBVH (lbvh.hpp): keys, sort and topology on the device; the node graph is then numbered into the
+// level-order wrapper array (one primitive per leaf wrapper -- pairing sibling leaves measured slower: both
+// primitives get tested on every visit; boxes are filled in later by run_box_kernels).  `order` receives the primitives' sorted order.
+template <typename real>
+int32_t build_lbvh(CrHandle* h, const std::vector<Prim<real>>& src, const std::vector<real>* bmin, const std::vector<real>* bmax,
+                   std::vector<int32_t>& order, std::vector<Entry<real>>& entries, std::vector<int32_t>& level_begin) {
+    const int32_t n = (int32_t)src.size();
+    entries.clear();
+    level_begin.assign(1, 0);
+    if (n == 0) return CR_OK;
+    LbvhBounds bnd;
+    for (int a = 0; a < 3; a++) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (int32_t i = 0; i < n; i++) {
+            const double cen = 0.5 * ((double)bmin[a][i] + (double)bmax[a][i]);
+            lo = std::min(lo, cen); hi = std::max(hi, cen);
+        }
+        bnd.lo[a] = std::isfinite(lo) ? lo : 0.0;
+        bnd.inv_ext[a] = (std::isfinite(hi - lo) && hi > lo) ? 1.0 / (hi - lo) : 0.0;
+    }
+    DevBuf d_src, d_keys, d_keys2, d_idx, d_idx2, d_tmp, d_children;
+    auto cleanup = [&] { d_src.release(); d_keys.release(); d_keys2.release(); d_idx.release(); d_idx2.release(); d_tmp.release(); d_children.release(); };
+#define LBVH_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(h, CR_ERR_HIP, hipGetErrorString(e_)); } } while (0)
+    LBVH_TRY(d_src.ensure((size_t)n * sizeof(Prim<real>)));
+    LBVH_TRY(hipMemcpyAsync(d_src.p, src.data(), (size_t)n * sizeof(Prim<real>), hipMemcpyHostToDevice, h->stream));
+    LBVH_TRY(d_keys.ensure((size_t)n * 8)); LBVH_TRY(d_keys2.ensure((size_t)n * 8));
+    LBVH_TRY(d_idx.ensure((size_t)n * 4)); LBVH_TRY(d_idx2.ensure((size_t)n * 4));
+    LBVH_TRY(d_children.ensure((size_t)std::max(1, n - 1) * 8));
+    const dim3 block(256), grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL((lbvh_key_kernel<real>), grid, block, 0, h->stream, (const Prim<real>*)d_src.p, n, bnd, (uint64_t*)d_keys.p, (int32_t*)d_idx.p);
+    LBVH_TRY(hipGetLastError());
+    size_t tmp_bytes = 0;
+    LBVH_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int32_t*)d_idx.p,
+                                                (int32_t*)d_idx2.p, n, 0, 63, h->stream));
+    LBVH_TRY(d_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
+    LBVH_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, (const uint64_t*)d_keys.p, (uint64_t*)d_keys2.p, (const int32_t*)d_idx.p,
+                                                (int32_t*)d_idx2.p, n, 0, 63, h->stream));
+    if (n >= 2) {
+        hipLaunchKernelGGL(lbvh_topology_kernel, dim3((unsigned)((n - 1 + 255) / 256)), block, 0, h->stream, (const uint64_t*)d_keys2.p, n, (int32_t*)d_children.p);
+        LBVH_TRY(hipGetLastError());
+    }
+    order.resize(n);
+    std::vector<int32_t> children((size_t)2 * std::max(1, n - 1));
+    LBVH_TRY(hipMemcpyAsync(order.data(), d_idx2.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    if (n >= 2) LBVH_TRY(hipMemcpyAsync(children.data(), d_children.p, (size_t)(n - 1) * 8, hipMemcpyDeviceToHost, h->stream));
+    LBVH_TRY(hipStreamSynchronize(h->stream));
+#undef LBVH_TRY
+    cleanup();
+    // node graph -> level-order wrappers with links (what relayout_bfs would produce from a pre-order array), in one
+    // breadth-first pass: a child < 0 is ~(sorted position of a primitive); siblings get adjacent indices
+    const int32_t total = 2 * n - 1;
+    entries.assign((size_t)total, Entry<real>());
+    level_begin.assign(1, 0);
+    if (n == 1) { entries[0].leaf = 0; entries[0].skip = 1; level_begin.push_back(1); return CR_OK; }
+    std::vector<int32_t> ref((size_t)total);   // node reference (as in `children`) of each new index
+    ref[0] = 0;
+    entries[0].skip = total;
+    int32_t level_first = 0, level_end = 1, next = 1;
+    std::vector<char> seen((size_t)(n - 1), 0);
+    while (level_first < level_end) {
+        for (int32_t k = level_first; k < level_end; k++) {
+            const int32_t r = ref[k];
+            Entry<real>& e = entries[k];
+            if (r < 0) { e.leaf = (~r) << 1; continue; }              // one primitive
+            if (r >= n - 1 || seen[r] || next + 2 > total) return fail(h, CR_ERR_HIP, "LBVH: malformed topology from the device");
+            seen[r] = 1;
+            const int32_t cl = children[2 * r], cr = children[2 * r + 1];
+            if ((cl < 0 && ~cl >= n) || (cr < 0 && ~cr >= n)) return fail(h, CR_ERR_HIP, "LBVH: malformed topology from the device");
+            e.leaf = -next;
+            ref[next] = cl; ref[next + 1] = cr;
+            entries[next].skip = next + 1;                            // after the left subtree comes the right child
+            entries[next + 1].skip = e.skip;                          // after the right subtree: whatever follows the parent
+            next += 2;
+        }
+        level_first = level_end; level_end = next;
+        level_begin.push_back(level_first);
+    }
+    entries.resize((size_t)next);
+    for (Entry<real>& e : entries) if (e.skip == total) e.skip = next;   // "no wrapper follows" = the final count
+    if (level_begin.back() != next) level_begin.push_back(next);
+    return CR_OK;
+}
+
 template <typename real> int32_t build_dev_scene(CrHandle* h) {
     DevScene<real>& ds = dev_scene<real>(h);
     if (ds.built) return CR_OK;
     auto t_begin = std::chrono::steady_clock::now();
+    const bool timing = getenv("CRUCIBLE_BUILD_TIMING") != nullptr;
+    auto lap = [&](const char* what) { if (timing) fprintf(stderr, "[build] %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };
     // visible primitives, in list order (bvhwrapper.rs:16-26)
     std::vector<int32_t> vis;
     for (size_t i = 0; i < h->prims.size(); i++) if (!(h->prims[i].flags & CR_PRIM_HIDDEN)) vis.push_back((int32_t)i);
@@ -424,7 +528,12 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
     }
     std::vector<int8_t> axis;
     ds.ordered = h->bvh_mode == CR_BVH_SAH_ORDERED;
-    if (n > 0 && h->bvh_mode != CR_BVH_REFERENCE) {
+    lap("primitive records and boxes");
+    const bool lbvh = h->bvh_mode == CR_BVH_LBVH;
+    if (lbvh) {
+        int32_t rc = build_lbvh<real>(h, src, b.bmin, b.bmax, b.order, b.entries, ds.level_begin);
+        if (rc != CR_OK) return rc;
+    } else if (n > 0 && h->bvh_mode != CR_BVH_REFERENCE) {
         SahBuilder<real> sb;
         sb.bmin = b.bmin; sb.bmax = b.bmax; sb.order = &b.order;
         sb.build_root(n);
@@ -432,6 +541,7 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
         relayout_bfs(b.entries, ds.level_begin, &axis);
     } else if (n > 0) { b.build_root(n); relayout_bfs(b.entries, ds.level_begin); }
     else ds.level_begin.assign(1, 0);
+    lap("tree");
     std::vector<Prim<real>> leaf_prims(n);
     for (int32_t i = 0; i < n; i++) leaf_prims[i] = src[b.order[i]];
 
@@ -528,6 +638,13 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
     ds.lds_bytes = r16(b.entries.size() * ds.entry_bytes) + r16(leaf_prims.size() * sizeof(Prim<real>)) +
                    r16(mats.size() * sizeof(Mat<real>)) + r16(texs.size() * sizeof(Tex<real>));
     ds.animated = any_keys;
+    if (lbvh && ds.n_entries > 0) {   // boxes: construction-time primitive boxes, bottom-up, on the device
+        int32_t rc = run_box_kernels<real>(h, ds, ds.entries.p, real(0), real(0), false);
+        if (rc != CR_OK) return rc;
+        HIP_TRY(h, hipMemcpyAsync(b.entries.data(), ds.entries.p, b.entries.size() * sizeof(Entry<real>), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    lap("uploads and boxes");
     ds.host_entries = b.entries;
     ds.host_axis = axis;
     ds.leaf_desc.resize(n);
@@ -899,17 +1016,7 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
         const size_t bytes = (size_t)ds.n_entries * ds.entry_bytes;
         HIP_TRY(h, ds.entries_refit.ensure(bytes));
         HIP_TRY(h, hipMemcpyAsync(ds.entries_refit.p, ds.entries.p, bytes, hipMemcpyDeviceToDevice, h->stream));
-        for (size_t l = ds.level_begin.size() - 1; l-- > 0;) {
-            const int32_t begin = ds.level_begin[l], end = ds.level_begin[l + 1];
-            if (end <= begin) continue;
-            const dim3 grid((unsigned)((end - begin + 255) / 256)), block(256);
-            const real ta = a.current_time, tb = a.current_time + a.shutter_length;
-            if (ds.ordered) hipLaunchKernelGGL((refit_level_kernel<real, true>), grid, block, 0, h->stream, (EntryO<real>*)ds.entries_refit.p,
-                                               begin, end, (const Prim<real>*)ds.prims.p, (const Key<real>*)ds.keys.p, ta, tb);
-            else hipLaunchKernelGGL((refit_level_kernel<real, false>), grid, block, 0, h->stream, (Entry<real>*)ds.entries_refit.p,
-                                    begin, end, (const Prim<real>*)ds.prims.p, (const Key<real>*)ds.keys.p, ta, tb);
-        }
-        HIP_TRY(h, hipGetLastError());
+        { int32_t rc = run_box_kernels<real>(h, ds, ds.entries_refit.p, a.current_time, a.current_time + a.shutter_length, true); if (rc != CR_OK) return rc; }
         a.entries = (const Entry<real>*)ds.entries_refit.p;
     }
     a.tiles_x = (uint32_t)(c.W + 7) / 8u; a.tiles_y = (uint32_t)(c.H + 7) / 8u;
@@ -1153,7 +1260,7 @@ int32_t cr_upload_scene(CrHandle* h, const CrSceneDesc* s) {
         if (p.kind == CR_PRIM_SPHERE && !(p.v[3] >= 0.0)) return fail(h, CR_ERR_INVALID_ARG, "Cannot make a sphere with negative radius");   // sphere.rs:26
     }
     if (s->sky_kind != CR_SKY_DEFAULT && s->sky_kind != CR_SKY_SPHERICAL) return fail(h, CR_ERR_INVALID_ARG, "unknown sky kind");
-    if (s->bvh_mode != CR_BVH_REFERENCE && s->bvh_mode != CR_BVH_SAH && s->bvh_mode != CR_BVH_SAH_ORDERED) return fail(h, CR_ERR_INVALID_ARG, "unknown bvh_mode");
+    if (s->bvh_mode < CR_BVH_REFERENCE || s->bvh_mode > CR_BVH_LBVH) return fail(h, CR_ERR_INVALID_ARG, "unknown bvh_mode");
     if (s->sky_kind == CR_SKY_SPHERICAL && (s->sky_image < 0 || s->sky_image >= s->n_images)) return fail(h, CR_ERR_INVALID_ARG, "sky image index out of range");
     for (int i = 0; i < s->n_images; i++)
         if (s->images[i].width < 1 || s->images[i].height < 1 || !s->images[i].rgb8) return fail(h, CR_ERR_INVALID_ARG, "bad image");

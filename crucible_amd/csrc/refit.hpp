@@ -48,14 +48,15 @@ template <typename real> CR_HD void enclose(real lo[3], real hi[3], const real b
     }
 }
 
-// Box of primitive p at time t, united into lo/hi.
+// Box of primitive p at time t, united into lo/hi.  use_keys = false: the construction-time box (no keys applied).
 template <typename real>
-CR_HD void prim_box_at(const Prim<real>& p, const Key<real>* keys, real t, bool before_start, real lo[3], real hi[3]) {
+CR_HD void prim_box_at(const Prim<real>& p, const Key<real>* keys, real t, bool before_start, real lo[3], real hi[3], bool use_keys = true) {
     real blo[3], bhi[3];
     const Key<real>* k = keys + p.key_first;
+    const int32_t n_keys = use_keys ? p.key_count : 0;
     if (p.kind() == 0) {   // Sphere::new, sphere.rs:29-30; Aabb::new_from_points, bvh.rs:44-64
         real c[3] = {p.g[0], p.g[1], p.g[2]}, r = p.g[3];
-        timeline_eval_side(k, p.key_count, t, before_start, c[0], c[1], c[2], r);
+        timeline_eval_side(k, n_keys, t, before_start, c[0], c[1], c[2], r);
         for (int a = 0; a < 3; a++) {
             real l = c[a] + (-r), h = c[a] + r;
             if (l <= h) { blo[a] = l; bhi[a] = h; } else { blo[a] = h; bhi[a] = l; }
@@ -65,7 +66,7 @@ CR_HD void prim_box_at(const Prim<real>& p, const Key<real>* keys, real t, bool 
         for (int j = 0; j < 3; j++) {
             real w = real(1);
             v[j][0] = p.g[3 * j]; v[j][1] = p.g[3 * j + 1]; v[j][2] = p.g[3 * j + 2];
-            timeline_eval_side(k, p.key_count, t, before_start, v[j][0], v[j][1], v[j][2], w);
+            timeline_eval_side(k, n_keys, t, before_start, v[j][0], v[j][1], v[j][2], w);
             v[j][0] = w * v[j][0]; v[j][1] = w * v[j][1]; v[j][2] = w * v[j][2];
         }
         for (int a = 0; a < 3; a++) {
@@ -78,9 +79,9 @@ CR_HD void prim_box_at(const Prim<real>& p, const Key<real>* keys, real t, bool 
 
 // Box of primitive p over ray times [ta, tb], united into lo/hi (rule in the header comment).
 template <typename real>
-CR_HD void prim_box_over(const Prim<real>& p, const Key<real>* keys, real ta, real tb, real lo[3], real hi[3]) {
-    prim_box_at(p, keys, ta, false, lo, hi);
-    if (p.key_count == 0) return;
+CR_HD void prim_box_over(const Prim<real>& p, const Key<real>* keys, real ta, real tb, real lo[3], real hi[3], bool use_keys = true) {
+    prim_box_at(p, keys, ta, false, lo, hi, use_keys);
+    if (!use_keys || p.key_count == 0) return;
     prim_box_at(p, keys, tb, false, lo, hi);
     for (int i = 0; i < p.key_count; i++) {
         const Key<real> k = keys[p.key_first + i];
@@ -95,9 +96,10 @@ CR_HD void prim_box_over(const Prim<real>& p, const Key<real>* keys, real ta, re
 #if defined(__HIPCC__)
 // One level of the tree, deepest level first (entries are stored level by level, children after parents):
 // leaves take their primitives' boxes, inner wrappers the union of their two children, already refitted.
+// use_keys = 0 gives the construction-time boxes (how the LBVH builder fills in its boxes).
 template <typename real, bool ORD>
 __global__ void refit_level_kernel(typename EntryOf<real, ORD>::type* entries, int32_t begin, int32_t end, const Prim<real>* prims,
-                                   const Key<real>* keys, real ta, real tb) {
+                                   const Key<real>* keys, real ta, real tb, int32_t use_keys) {
     const int32_t i = begin + (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= end) return;
     const int32_t leaf = entries[i].leaf;
@@ -105,7 +107,7 @@ __global__ void refit_level_kernel(typename EntryOf<real, ORD>::type* entries, i
     for (int a = 0; a < 3; a++) { lo[a] = r_inf(real(0)); hi[a] = -r_inf(real(0)); }
     if (leaf >= 0) {
         const int32_t first = leaf >> 1, count = (leaf & 1) + 1;
-        for (int32_t k = 0; k < count; k++) prim_box_over(prims[first + k], keys, ta, tb, lo, hi);
+        for (int32_t k = 0; k < count; k++) prim_box_over(prims[first + k], keys, ta, tb, lo, hi, use_keys != 0);
     } else {
         const int32_t li = ORD ? ordered_left(leaf) : -leaf;   // siblings are adjacent in the level-order array
         const real* l = entries[li].b;

@@ -4,7 +4,7 @@
 // Extras (not in the reference): --width, --samples, --seed, --scene-seed, --real f32|f64, --device,
 // --format ppm|p6|png (frame files: the reference's ASCII P3, binary PPM, PNG),
 // --sky FILE.hdr (Radiance map as the spherical skybox; world 5 = demo_images::garden_skybox needs it),
-// --bvh reference|sah|ordered (the tree cr_upload_scene builds; reference = the parity mode, default), --refit (re-derive
+// --bvh reference|sah|ordered|lbvh (the tree cr_upload_scene builds; reference = the parity mode, default), --refit (re-derive
 // the wrapper boxes per frame so keyframed primitives are not clipped; the reference does not),
 // --dump-desc FILE (write the flattened scene description and exit; used by the tests to check
 // this mirror against the Python one).
@@ -96,8 +96,8 @@ int main(int argc, char** argv) {
         if (!sky.empty() && world != 5) scene.load_spherical_skybox(RTWImage::load_hdr(sky));
         scene.seed = seed; scene.device = device;
         scene.real_type = real == "f64" ? CR_REAL_F64 : CR_REAL_F32;
-        if (bvh != "reference" && bvh != "sah" && bvh != "ordered") { fprintf(stderr, "--bvh takes reference, sah or ordered\n"); return 2; }
-        scene.bvh_mode = bvh == "sah" ? CR_BVH_SAH : (bvh == "ordered" ? CR_BVH_SAH_ORDERED : CR_BVH_REFERENCE);
+        if (bvh != "reference" && bvh != "sah" && bvh != "ordered" && bvh != "lbvh") { fprintf(stderr, "--bvh takes reference, sah, ordered or lbvh\n"); return 2; }
+        scene.bvh_mode = bvh == "sah" ? CR_BVH_SAH : (bvh == "ordered" ? CR_BVH_SAH_ORDERED : (bvh == "lbvh" ? CR_BVH_LBVH : CR_BVH_REFERENCE));
         scene.refit_boxes = refit;
         if (format != "ppm" && format != "p6" && format != "png") { fprintf(stderr, "--format takes ppm, p6 or png\n"); return 2; }
         scene.frame_format = format;

@@ -155,8 +155,12 @@ typedef struct CrKeyframe {
  *                     then right); the closest hit again differs from the reference tree's only on box-grazing
  *                     rays.  Stackless on the device (one skip link per direction octant).  Megakernel
  *                     pipeline only.
+ *   CR_BVH_LBVH       SURVEY 8(f) row 1, "GPU LBVH": the tree is built on the device (Morton keys of the
+ *                     primitive-box centroids, radix sort, Karras' topology; one primitive per leaf) in a few
+ *                     milliseconds instead of the host builders' 0.3-0.4 s per million primitives.  Walked in
+ *                     BVHWrapper::hit's order like CR_BVH_SAH; a lower-quality tree than SAH.
  */
-enum { CR_BVH_REFERENCE = 0, CR_BVH_SAH = 1, CR_BVH_SAH_ORDERED = 2 };
+enum { CR_BVH_REFERENCE = 0, CR_BVH_SAH = 1, CR_BVH_SAH_ORDERED = 2, CR_BVH_LBVH = 3 };
 
 typedef struct CrSceneDesc {
     int32_t n_prims;
@@ -166,7 +170,7 @@ typedef struct CrSceneDesc {
     int32_t n_keys;
     int32_t sky_kind;
     int32_t sky_image;
-    int32_t bvh_mode;       /* CR_BVH_REFERENCE (0) | CR_BVH_SAH | CR_BVH_SAH_ORDERED */
+    int32_t bvh_mode;       /* CR_BVH_REFERENCE (0) | CR_BVH_SAH | CR_BVH_SAH_ORDERED | CR_BVH_LBVH */
     const CrPrimitive* prims;
     const CrMaterial* materials;
     const CrTexture* textures;

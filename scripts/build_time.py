@@ -4,7 +4,7 @@ from crucible_amd.demo_builder import million_spheres
 from crucible_amd.renderer import Renderer
 from crucible_amd import _abi as A
 t=time.time(); sc = million_spheres(1, scene_seed=1, image_width=64, samples=1); print("gen %.2fs" % (time.time()-t))
-sc.bvh_mode = {"sah": A.CR_BVH_SAH, "ordered": A.CR_BVH_SAH_ORDERED}.get(os.environ.get("BVH"), A.CR_BVH_REFERENCE)
+sc.bvh_mode = {"sah": A.CR_BVH_SAH, "ordered": A.CR_BVH_SAH_ORDERED, "lbvh": A.CR_BVH_LBVH}.get(os.environ.get("BVH"), A.CR_BVH_REFERENCE)
 r = Renderer(0)
 t=time.time(); r.upload_scene(sc.flatten()); print("upload %.2fs" % (time.time()-t))
 for rt in (A.CR_REAL_F32, A.CR_REAL_F64):

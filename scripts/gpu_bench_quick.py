@@ -10,7 +10,7 @@ w = int(sys.argv[1]) if len(sys.argv) > 1 else 1920
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 modes = sys.argv[3] if len(sys.argv) > 3 else "f32"
 sc = book1_end_scene(1, scene_seed=1, image_width=w, samples=spp)
-sc.bvh_mode = {"sah": A.CR_BVH_SAH, "ordered": A.CR_BVH_SAH_ORDERED}.get(os.environ.get("BVH"), A.CR_BVH_REFERENCE)
+sc.bvh_mode = {"sah": A.CR_BVH_SAH, "ordered": A.CR_BVH_SAH_ORDERED, "lbvh": A.CR_BVH_LBVH}.get(os.environ.get("BVH"), A.CR_BVH_REFERENCE)
 r = Renderer(0)
 r.upload_scene(sc.flatten())
 for name in modes.split(","):

@@ -1,4 +1,4 @@
-"""the CR_BVH_SAH quality builder and cr_export_bvh.
+"""the CR_BVH_SAH quality builder, the device-built CR_BVH_LBVH tree, and cr_export_bvh.
 
 The reference builds only its median-split tree (src/objects/bvhwrapper.rs:46-78), so nothing of the reference's
 pins the SAH topology.  What is pinned:
@@ -72,7 +72,7 @@ def check_tree(boxes, kids, vis):
                 lo_ok = (boxes[c, 0::2] >= boxes[k, 0::2]).all() and (boxes[c, 1::2] <= boxes[k, 1::2]).all()
                 assert lo_ok, "child box not inside its parent's"
         leaf = [~c for c in kids[k] if c < 0]
-        assert len(leaf) in (0, 2), "a wrapper holds two wrappers or two primitives"
+        assert len(leaf) in (0, 2), "a wrapper holds two wrappers or two primitives (one primitive: named twice)"
         seen += sorted(set(leaf))
     assert sorted(seen) == sorted(vis), "every visible primitive in exactly one leaf"
     assert n <= max(1, 2 * len(vis) - 1)
@@ -82,7 +82,7 @@ def check_tree(boxes, kids, vis):
 @pytest.mark.parametrize("build", [lambda: book1_end_scene(1, scene_seed=2, image_width=32, samples=1),
                                    lambda: scenes.mixed_scene(32, 1), lambda: scenes.few_spheres(3),
                                    lambda: scenes.few_spheres(9)], ids=["book1", "mixed", "three", "nine"])
-@pytest.mark.parametrize("mode", [A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED], ids=["sah", "ordered"])
+@pytest.mark.parametrize("mode", [A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED, A.CR_BVH_LBVH], ids=["sah", "ordered", "lbvh"])
 def test_sah_tree_is_well_formed(renderer, rt, tag, build, mode):
     sc = build()
     flat = upload(renderer, sc, mode)
@@ -104,7 +104,7 @@ def test_sah_tree_is_well_formed(renderer, rt, tag, build, mode):
     ("few2", lambda: scenes.few_spheres(2), SEED), ("few3", lambda: scenes.few_spheres(3), SEED),
     ("few9", lambda: scenes.few_spheres(9), SEED),
 ])
-@pytest.mark.parametrize("mode", [A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED], ids=["sah", "ordered"])
+@pytest.mark.parametrize("mode", [A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED, A.CR_BVH_LBVH], ids=["sah", "ordered", "lbvh"])
 def test_sah_mode_bit_exact_against_oracle_on_the_same_tree(renderer, oracles, rt, tag, name, build, seed, mode):
     sc = build()
     flat = upload(renderer, sc, mode)
@@ -120,7 +120,7 @@ def test_sah_mode_bit_exact_against_oracle_on_the_same_tree(renderer, oracles, r
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
-@pytest.mark.parametrize("mode", [A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED], ids=["sah", "ordered"])
+@pytest.mark.parametrize("mode", [A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED, A.CR_BVH_LBVH], ids=["sah", "ordered", "lbvh"])
 def test_sah_teapot_against_oracle(renderer, oracles, rt, tag, mode):
     """6320 triangles + image sky: libm carve-out as in test_gpu_parity (acos/atan2/asin), so 1e-4 on >= 99.9 %."""
     sc = load_teapot(1, image_width=96, samples=2, sky=procedural_sky(256, 128))
@@ -134,7 +134,7 @@ def test_sah_teapot_against_oracle(renderer, oracles, rt, tag, mode):
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
-@pytest.mark.parametrize("mode", [A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED], ids=["sah", "ordered"])
+@pytest.mark.parametrize("mode", [A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED, A.CR_BVH_LBVH], ids=["sah", "ordered", "lbvh"])
 def test_sah_agrees_with_reference_topology(renderer, rt, tag, mode):
     """Same closest hits except for rays grazing a box face: nearly all pixels identical, far fewer box tests."""
     sc = book1_end_scene(1, scene_seed=1, image_width=320, samples=8)
@@ -145,7 +145,8 @@ def test_sah_agrees_with_reference_topology(renderer, rt, tag, mode):
     same = (img == ref).all(axis=2).mean()
     assert same >= 0.995, same
     assert np.abs(img.astype(np.float64) - ref.astype(np.float64)).mean() < 1e-4
-    assert st["node_tests"] < 0.8 * rst["node_tests"], (st["node_tests"], rst["node_tests"])
+    if mode != A.CR_BVH_LBVH:   # the Morton tree is built for speed of construction, not of traversal
+        assert st["node_tests"] < 0.8 * rst["node_tests"], (st["node_tests"], rst["node_tests"])
 
 
 def test_unknown_bvh_mode_is_rejected(renderer):

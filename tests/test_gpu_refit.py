@@ -27,7 +27,8 @@ def render(renderer, sc, rt, mode, refit):
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
-@pytest.mark.parametrize("mode", [A.CR_BVH_REFERENCE, A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED], ids=["reference", "sah", "ordered"])
+@pytest.mark.parametrize("mode", [A.CR_BVH_REFERENCE, A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED, A.CR_BVH_LBVH],
+                         ids=["reference", "sah", "ordered", "lbvh"])
 @pytest.mark.parametrize("frame", [0, 1, 2, 5])
 def test_refit_bit_exact_against_oracle_refit(renderer, oracles, rt, tag, mode, frame):
     sc = scenes.moving_scene(96, 4, frame=frame)
@@ -40,7 +41,8 @@ def test_refit_bit_exact_against_oracle_refit(renderer, oracles, rt, tag, mode, 
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
-@pytest.mark.parametrize("mode", [A.CR_BVH_REFERENCE, A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED], ids=["reference", "sah", "ordered"])
+@pytest.mark.parametrize("mode", [A.CR_BVH_REFERENCE, A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED, A.CR_BVH_LBVH],
+                         ids=["reference", "sah", "ordered", "lbvh"])
 def test_stale_boxes_still_match_the_oracle(renderer, oracles, rt, tag, mode):
     """refit_boxes = 0 on the same scene: the reference's (clipped) image, bit-exact as before."""
     sc = scenes.moving_scene(96, 4, frame=0)
@@ -68,7 +70,8 @@ def test_refit_agrees_with_the_linear_list_and_stale_boxes_do_not(renderer, orac
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
-@pytest.mark.parametrize("mode", [A.CR_BVH_REFERENCE, A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED], ids=["reference", "sah", "ordered"])
+@pytest.mark.parametrize("mode", [A.CR_BVH_REFERENCE, A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED, A.CR_BVH_LBVH],
+                         ids=["reference", "sah", "ordered", "lbvh"])
 def test_refit_of_motionless_keys_changes_nothing(renderer, rt, tag, mode):
     """Keys with zero offsets: the refit kernels run (the scene has primitive keys) and must reproduce the
     construction-time boxes exactly."""
