@@ -12,4 +12,6 @@ python bench.py --workload movie --no-cpu-baseline --steps 3 > gpurun_out/r01f/b
 for b in sah ordered; do python bench.py --bvh $b --no-cpu-baseline --steps 3 > gpurun_out/r01f/bench_$b.json 2>/dev/null; echo $b done; done
 python bench.py --workload teapot --bvh sah --no-cpu-baseline --steps 2 > gpurun_out/r01f/bench_teapot_sah.json 2>/dev/null
 python bench.py --workload million --bvh sah --no-cpu-baseline --steps 2 > gpurun_out/r01f/bench_million_sah.json 2>/dev/null; echo sah extras done
+python bench.py --bvh lbvh --no-cpu-baseline --steps 3 > gpurun_out/r01f/bench_lbvh.json 2>/dev/null
+python bench.py --workload million --bvh lbvh --no-cpu-baseline --steps 2 > gpurun_out/r01f/bench_million_lbvh.json 2>/dev/null; echo lbvh done
 SPP=512 bash scripts/profile_pmc.sh
