@@ -445,6 +445,15 @@ public:
         return f;
     }
 
+    // movie_maker::make_mp4's ffmpeg invocation (scene/movie_maker.rs:6-33) for the frames render_movie wrote, as an
+    // argument vector.  The reference runs it; this mirror hands it to the caller ("optional
+    // ffmpeg hand-off"): a process that has initialised the GPU must not exec another program on this pool.
+    std::vector<std::string> mp4_command(const std::string& fname, size_t padding) const {
+        const std::string ext = frame_format == "png" ? ".png" : ".ppm";
+        return {"ffmpeg", "-framerate", std::to_string(frame_rate), "-i", fname + "/artifacts/image%0" + std::to_string(padding) + "d" + ext,
+                "-vf", "scale=trunc(iw/2)*2:trunc(ih/2)*2", "-c:v", "libx264", "-pix_fmt", "yuv420p", "-crf", "25", fname + "/movie.mp4"};
+    }
+
     size_t compute_frame_count() const { return (size_t)std::ceil(duration * (double)frame_rate); }   // scene/mod.rs:324-330
 
     // ---- Camera::render over the library (scene/mod.rs:283-347)
@@ -505,6 +514,11 @@ public:
                     scene_cam.next_frame();
                 }
                 for (int k = 0; k < 2; k++) if (writers[k].joinable()) { writers[k].join(); if (rc == CR_OK) rc = write_rc[k]; }
+                if (rc == CR_OK) {   // scene/mod.rs:319 would run this
+                    std::string cmd;
+                    for (const std::string& a : mp4_command(fname, digits)) cmd += (cmd.empty() ? "" : " ") + (a.find_first_of("*()") != std::string::npos ? "'" + a + "'" : a);
+                    fprintf(stderr, "Frames written. To assemble the movie: %s\n", cmd.c_str());
+                }
             }
         }
         if (rc != CR_OK) fprintf(stderr, "Render failed. %s\n", cr_last_error(h));

@@ -515,6 +515,13 @@ class Scene:
             if own:
                 r.close()
 
+    def mp4_command(self, fname, padding, ext=".ppm"):
+        """movie_maker::make_mp4's ffmpeg argument vector (scene/movie_maker.rs:6-33).  The reference runs it after
+        the last frame; here it is returned to the caller (a process that holds the GPU does not exec others)."""
+        return ["ffmpeg", "-framerate", str(self.frame_rate), "-i", f"{fname}/artifacts/image%0{padding}d{ext}",
+                "-vf", "scale=trunc(iw/2)*2:trunc(ih/2)*2", "-c:v", "libx264", "-pix_fmt", "yuv420p", "-crf", "25",
+                f"{fname}/movie.mp4"]
+
     def render_movie(self, fname):
         from .renderer import Renderer
         os.mkdir(fname)   # scene/mod.rs:296: fails if it exists

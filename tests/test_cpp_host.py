@@ -106,6 +106,18 @@ def test_cli_movie_writes_frames(cli, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_movie_prints_the_references_ffmpeg_command(cli, tmp_path):
+    """movie_maker::make_mp4 (scene/movie_maker.rs:6-33): same arguments, handed to the caller instead of executed."""
+    stem = str(tmp_path / "mov")
+    r = subprocess.run([cli, "--file", stem, "--world", "1", "--movie", "--seconds", "0.5", "--rate", "4", "--width", "32",
+                        "--samples", "1"], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0
+    want = (f"ffmpeg -framerate 4 -i {stem}/artifacts/image%01d.ppm -vf 'scale=trunc(iw/2)*2:trunc(ih/2)*2' -c:v libx264 "
+            f"-pix_fmt yuv420p -crf 25 {stem}/movie.mp4")
+    assert want in r.stderr, r.stderr
+
+
+@pytest.mark.gpu
 def test_cli_movie_frame_formats_hold_the_same_pixels(cli, tmp_path):
     """--format p6 / png, written by the helper thread while the next frame renders: same bytes
     per channel as the reference's ASCII P3, frame for frame."""

@@ -293,3 +293,13 @@ def test_radiance_decoder(tmp_path, monkeypatch, mode, flip):
     assert got.shape == (9, 40, 3)
     assert np.array_equal(got, _expected_rgb8(rgbe))
     assert got.max() == 255 and got.min() == 0     # clamped highlights, black row
+
+
+def test_mp4_command_is_the_references_ffmpeg_call():
+    """scene/movie_maker.rs:6-33: the argument list, with the frame pattern of render_movie (scene/mod.rs:295-322)."""
+    from crucible_amd.demo_builder import book1_end_scene
+    sc = book1_end_scene(1, scene_seed=1, image_width=32, samples=1)
+    sc.frame_rate = 24
+    assert sc.mp4_command("out", 3) == ["ffmpeg", "-framerate", "24", "-i", "out/artifacts/image%03d.ppm", "-vf",
+                                        "scale=trunc(iw/2)*2:trunc(ih/2)*2", "-c:v", "libx264", "-pix_fmt", "yuv420p",
+                                        "-crf", "25", "out/movie.mp4"]
