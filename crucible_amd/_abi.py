@@ -1,7 +1,7 @@
 """ctypes mirror of include/crucible_hip.h (the C ABI).  Plain data only."""
 import ctypes as C
 
-CR_ABI_VERSION = 1
+CR_ABI_VERSION = 2
 
 CR_OK, CR_ERR_INVALID_ARG, CR_ERR_NO_DEVICE, CR_ERR_HIP, CR_ERR_NO_SCENE, CR_ERR_IO, CR_ERR_NAN, CR_ERR_UNSUPPORTED = range(8)
 CR_REAL_F32, CR_REAL_F64 = 0, 1
@@ -11,7 +11,8 @@ CR_MAT_LAMBERTIAN, CR_MAT_METAL, CR_MAT_DIELECTRIC = 0, 1, 2
 CR_TEX_SOLID, CR_TEX_CHECKER, CR_TEX_IMAGE = 0, 1, 2
 CR_SKY_DEFAULT, CR_SKY_SPHERICAL = 0, 1
 CR_BVH_REFERENCE, CR_BVH_SAH, CR_BVH_SAH_ORDERED, CR_BVH_LBVH = 0, 1, 2, 3
-CR_KEY_TX, CR_KEY_TY, CR_KEY_TZ, CR_KEY_RADIUS = 0, 1, 2, 3
+CR_KEY_TX, CR_KEY_TY, CR_KEY_TZ, CR_KEY_RADIUS, CR_KEY_SCALE_X, CR_KEY_SCALE_Y, CR_KEY_SCALE_Z = 0, 1, 2, 3, 4, 5, 6
+CR_MAX_CHECKER_DEPTH = 32
 CR_KEY_NERP, CR_KEY_LERP = 0, 1
 
 
@@ -69,6 +70,12 @@ class CrStats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class CrGroupStats(C.Structure):
+    _fields_ = [("render", CrStats), ("reduce_ms", C.c_double), ("members", C.c_int32), ("used_rccl", C.c_int32)]
+
+
+CR_GROUP_ID_BYTES = 128
+
 # every symbol include/crucible_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "cr_abi_version": (C.c_int32, []),
@@ -89,6 +96,19 @@ SYMBOLS = {
     "cr_write_png": (C.c_int32, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "cr_quantize_rgb8": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
     "cr_last_error": (C.c_char_p, [C.c_void_p]),
+    "cr_group_shard": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "cr_group_create": (C.c_int32, [C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]),
+    "cr_group_unique_id": (C.c_int32, [C.c_void_p]),
+    "cr_group_create_rank": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cr_group_destroy": (None, [C.c_void_p]),
+    "cr_group_local_size": (C.c_int32, [C.c_void_p]),
+    "cr_group_size": (C.c_int32, [C.c_void_p]),
+    "cr_group_rank": (C.c_int32, [C.c_void_p]),
+    "cr_group_handle": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "cr_group_upload_scene": (C.c_int32, [C.c_void_p, C.POINTER(CrSceneDesc)]),
+    "cr_group_render": (C.c_int32, [C.c_void_p, C.POINTER(CrCameraDesc), C.POINTER(CrRenderParams), C.c_void_p,
+                                    C.POINTER(CrGroupStats)]),
+    "cr_group_last_error": (C.c_char_p, [C.c_void_p]),
 }
 
 

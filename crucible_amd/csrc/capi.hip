@@ -83,6 +83,15 @@ struct CrHandle {
     DevScene<float> s32;
     DevScene<double> s64;
     DevBuf work_counter, counters, att_stack, out_buf;
+    // Camera keyframes of a render travel in a ring of per-launch slots: a pinned host slot is filled, copied to its
+    // device slot on the handle's stream and kept until that copy's event has fired, so back-to-back asynchronous
+    // renders (a movie's frames) never see each other's keys.
+    static constexpr int kCamSlots = 4;
+    static constexpr size_t kMaxCamKeys = 512;
+    void* cam_host[kCamSlots] = {};
+    DevBuf cam_dev[kCamSlots];
+    hipEvent_t cam_ev[kCamSlots] = {};
+    int cam_next = 0, cam_pending_slot = -1;
     DevBuf sample_buf, sg_acc;   // sample-granular megakernel: per-sample colours of a batch, running sums between batches
     // wavefront pipeline state (wavefront.hpp)
     DevBuf wf_job, wf_rng, wf_ray, wf_depth, wf_hit_t, wf_hit_prim, wf_chunk, wf_ctrl, wf_samples, wf_acc;
@@ -588,10 +597,8 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
         for (int k = 0; k < 3; k++) o.color[k] = (real)t.color[k];
         texs.push_back(o);
     }
-    // scene keys, then room for the camera's keys (copied per render)
-    const size_t kMaxCamKeys = 512;
-    std::vector<Key<real>> keys(h->keys.size() + kMaxCamKeys);
-    memset(keys.data(), 0, keys.size() * sizeof(Key<real>));
+    std::vector<Key<real>> keys(h->keys.size());
+    if (!keys.empty()) memset(keys.data(), 0, keys.size() * sizeof(Key<real>));
     for (size_t i = 0; i < h->keys.size(); i++) {
         const CrKeyframe& k = h->keys[i];
         keys[i].t0 = (real)k.t0; keys[i].t1 = (real)k.t1; keys[i].a = (real)k.a; keys[i].b = (real)k.b;
@@ -960,6 +967,22 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     int32_t rc = build_dev_scene<real>(h);
     if (rc != CR_OK) return rc;
     DevScene<real>& ds = dev_scene<real>(h);
+    if (p->sample_count == 0) {
+        // An empty shard (more ranks than samples): the sum of no samples, and 0 / samples for the mean, are both
+        // zero -- cast_ray's loop body never runs (ray_casting.rs:82).  No kernel is launched.
+        const size_t bytes = (size_t)cd->image_width * (size_t)cd->image_height * 3 * sizeof(real);
+        HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+        HIP_TRY(h, hipMemsetAsync(d_out, 0, bytes, h->stream));
+        HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+        if (stats) {
+            HIP_TRY(h, hipEventSynchronize(h->ev1));
+            float ms = 0;
+            HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+            memset(stats, 0, sizeof *stats);
+            stats->kernel_ms = ms; stats->upload_ms = h->upload_ms; stats->bvh_entries = ds.n_entries;
+        }
+        return CR_OK;
+    }
     KernelArgs<real> a;
     memset(&a, 0, sizeof a);
     a.entries = (const Entry<real>*)ds.entries.p; a.prims = (const Prim<real>*)ds.prims.p;
@@ -988,14 +1011,25 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     c.vup = mk<real>((real)cd->vup[0], (real)cd->vup[1], (real)cd->vup[2]);
     int nk = cd->from_key_count + cd->at_key_count;
     c.animated = nk > 0;
-    if (nk > 512) return fail(h, CR_ERR_UNSUPPORTED, "more than 512 camera keyframes");
-    c.from_key_first = ds.n_scene_keys; c.from_key_count = cd->from_key_count;
-    c.at_key_first = ds.n_scene_keys + cd->from_key_count; c.at_key_count = cd->at_key_count;
-    if (nk > 0) {
-        std::vector<Key<real>> ck(nk);
+    if ((size_t)nk > CrHandle::kMaxCamKeys) return fail(h, CR_ERR_UNSUPPORTED, "more than 512 camera keyframes");
+    c.from_key_first = 0; c.from_key_count = cd->from_key_count;
+    c.at_key_first = cd->from_key_count; c.at_key_count = cd->at_key_count;
+    a.cam_keys = nullptr;
+    if (nk > 0) {   // per-launch slot: never overwritten while an earlier render may still read it
+        const int slot = h->cam_next;
+        h->cam_next = (slot + 1) % CrHandle::kCamSlots;
+        const size_t slot_bytes = CrHandle::kMaxCamKeys * sizeof(Key<double>);
+        if (!h->cam_host[slot]) {
+            HIP_TRY(h, hipHostMalloc(&h->cam_host[slot], slot_bytes, hipHostMallocDefault));
+            HIP_TRY(h, h->cam_dev[slot].ensure(slot_bytes));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->cam_ev[slot], hipEventDisableTiming));
+        } else HIP_TRY(h, hipEventSynchronize(h->cam_ev[slot]));   // the slot's previous user has finished with it
+        Key<real>* ck = (Key<real>*)h->cam_host[slot];
         for (int i = 0; i < cd->from_key_count; i++) key_to_real(cd->from_keys[i], ck[i]);
         for (int i = 0; i < cd->at_key_count; i++) key_to_real(cd->at_keys[i], ck[cd->from_key_count + i]);
-        HIP_TRY(h, hipMemcpy((Key<real>*)ds.keys.p + ds.n_scene_keys, ck.data(), nk * sizeof(Key<real>), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpyAsync(h->cam_dev[slot].p, ck, nk * sizeof(Key<real>), hipMemcpyHostToDevice, h->stream));
+        a.cam_keys = (const Key<real>*)h->cam_dev[slot].p;
+        h->cam_pending_slot = slot;
     }
     {   // static camera: same expression tree the kernel would evaluate per sample
         V3<real> from = mk<real>(real(0) + c.from.x, real(0) + c.from.y, real(0) + c.from.z);
@@ -1091,6 +1125,11 @@ int32_t validate_render(CrHandle* h, const CrCameraDesc* cam, const CrRenderPara
     if (!(p->frame_rate > 0)) return fail(h, CR_ERR_INVALID_ARG, "frame_rate must be positive");
     if ((cam->from_key_count > 0 && !cam->from_keys) || (cam->at_key_count > 0 && !cam->at_keys) || cam->from_key_count < 0 || cam->at_key_count < 0)
         return fail(h, CR_ERR_INVALID_ARG, "camera keyframe array missing");
+    for (int i = 0; i < cam->from_key_count + cam->at_key_count; i++) {   // cam_translate_* only (scene_animator.rs)
+        const CrKeyframe& k = i < cam->from_key_count ? cam->from_keys[i] : cam->at_keys[i - cam->from_key_count];
+        if (k.channel < CR_KEY_TX || k.channel > CR_KEY_TZ || (k.interp != CR_KEY_NERP && k.interp != CR_KEY_LERP))
+            return fail(h, CR_ERR_INVALID_ARG, "camera keyframes are translations (channels 0..2)");
+    }
     return CR_OK;
 }
 
@@ -1210,6 +1249,11 @@ void cr_destroy(CrHandle* h) {
     h->att_stack.release(); h->out_buf.release(); h->sample_buf.release(); h->sg_acc.release();
     h->wf_job.release(); h->wf_rng.release(); h->wf_ray.release(); h->wf_depth.release(); h->wf_hit_t.release(); h->wf_hit_prim.release();
     h->wf_chunk.release(); h->wf_ctrl.release(); h->wf_samples.release(); h->wf_acc.release();
+    for (int i = 0; i < CrHandle::kCamSlots; i++) {
+        if (h->cam_host[i]) (void)hipHostFree(h->cam_host[i]);
+        h->cam_dev[i].release();
+        if (h->cam_ev[i]) (void)hipEventDestroy(h->cam_ev[i]);
+    }
     if (h->wf_ring_host) { (void)hipHostFree(h->wf_ring_host); for (int i = 0; i < 8; i++) if (h->wf_ev[i]) (void)hipEventDestroy(h->wf_ev[i]); }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1234,6 +1278,15 @@ int32_t cr_upload_scene(CrHandle* h, const CrSceneDesc* s) {
         if (t.kind == CR_TEX_SOLID) for (int k = 0; k < 3; k++) if (!(t.color[k] >= 0.0 && t.color[k] <= 1.0))
             return fail(h, CR_ERR_INVALID_ARG, "colour component outside [0,1]");   // Color::new, utils.rs:345-350
     }
+    {   // the device resolves a checker chain iteratively with a bound of 32 levels (pathtrace.hpp, shade)
+        std::vector<int32_t> depth((size_t)s->n_textures, 0);
+        for (int i = 0; i < s->n_textures; i++) {
+            const CrTexture& t = s->textures[i];
+            if (t.kind != CR_TEX_CHECKER) continue;
+            depth[i] = 1 + std::max(depth[t.even], depth[t.odd]);
+            if (depth[i] > CR_MAX_CHECKER_DEPTH) return fail(h, CR_ERR_UNSUPPORTED, "checker textures nested deeper than CR_MAX_CHECKER_DEPTH (32)");
+        }
+    }
     for (int i = 0; i < s->n_materials; i++) {
         const CrMaterial& m = s->materials[i];
         if (m.kind < CR_MAT_LAMBERTIAN || m.kind > CR_MAT_DIELECTRIC) return fail(h, CR_ERR_INVALID_ARG, "unknown material kind");
@@ -1247,7 +1300,7 @@ int32_t cr_upload_scene(CrHandle* h, const CrSceneDesc* s) {
     }
     for (int i = 0; i < s->n_keys; i++) {
         const CrKeyframe& k = s->keys[i];
-        if (k.channel < CR_KEY_TX || k.channel > CR_KEY_RADIUS || (k.interp != CR_KEY_NERP && k.interp != CR_KEY_LERP))
+        if (k.channel < CR_KEY_TX || k.channel > CR_KEY_SCALE_Z || (k.interp != CR_KEY_NERP && k.interp != CR_KEY_LERP))
             return fail(h, CR_ERR_INVALID_ARG, "bad keyframe");
     }
     for (int i = 0; i < s->n_prims; i++) {
@@ -1255,6 +1308,11 @@ int32_t cr_upload_scene(CrHandle* h, const CrSceneDesc* s) {
         if (p.kind != CR_PRIM_SPHERE && p.kind != CR_PRIM_TRIANGLE) return fail(h, CR_ERR_INVALID_ARG, "unknown primitive kind");
         if (p.material < 0 || p.material >= s->n_materials) return fail(h, CR_ERR_INVALID_ARG, "primitive material index out of range");
         if (p.key_count < 0 || p.key_first < 0 || p.key_first + p.key_count > s->n_keys) return fail(h, CR_ERR_INVALID_ARG, "primitive keyframe range out of bounds");
+        for (int k = 0; k < p.key_count; k++) {   // the Scene API type-checks scale keys (scene_animator.rs:38-183)
+            const int32_t ch = s->keys[p.key_first + k].channel;
+            if (p.kind == CR_PRIM_SPHERE && ch > CR_KEY_RADIUS) return fail(h, CR_ERR_INVALID_ARG, "ScaleX/ScaleY/ScaleZ cannot apply to Spheres");
+            if (p.kind == CR_PRIM_TRIANGLE && ch == CR_KEY_RADIUS) return fail(h, CR_ERR_INVALID_ARG, "ScaleR can only be applied to Spheres");
+        }
         int nv = p.kind == CR_PRIM_SPHERE ? 4 : 9;
         for (int k = 0; k < nv; k++) if (!finite(p.v[k])) return fail(h, CR_ERR_INVALID_ARG, "primitive coordinate is not finite");
         if (p.kind == CR_PRIM_SPHERE && !(p.v[3] >= 0.0)) return fail(h, CR_ERR_INVALID_ARG, "Cannot make a sphere with negative radius");   // sphere.rs:26
@@ -1304,8 +1362,14 @@ int32_t cr_render_device(CrHandle* h, const CrCameraDesc* cam, const CrRenderPar
     if (rc != CR_OK) return rc;
     if (!d_out) return fail(h, CR_ERR_INVALID_ARG, "output buffer is null");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (p->real_type == CR_REAL_F64) return render_typed<double>(h, cam, p, d_out, stats);
-    return render_typed<float>(h, cam, p, d_out, stats);
+    h->cam_pending_slot = -1;
+    rc = p->real_type == CR_REAL_F64 ? render_typed<double>(h, cam, p, d_out, stats) : render_typed<float>(h, cam, p, d_out, stats);
+    if (h->cam_pending_slot >= 0) {   // the camera-key slot is free again once everything queued so far has run
+        hipError_t e = hipEventRecord(h->cam_ev[h->cam_pending_slot], h->stream);
+        h->cam_pending_slot = -1;
+        if (e != hipSuccess && rc == CR_OK) { h->error = std::string("hipEventRecord: ") + hipGetErrorString(e); rc = CR_ERR_HIP; }
+    }
+    return rc;
 }
 
 int32_t cr_render_host(CrHandle* h, const CrCameraDesc* cam, const CrRenderParams* p, void* h_out, CrStats* stats) {
@@ -1452,5 +1516,181 @@ int32_t cr_write_png(const char* path, const void* rgb, int32_t real_type, int32
 }
 
 const char* cr_last_error(CrHandle* h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+}   // extern "C"
+
+// ================================================================== groups of devices (group.hpp)
+#include "group.hpp"
+
+extern "C" {
+
+int32_t cr_group_shard(int32_t samples, int32_t member, int32_t n_members, int32_t* begin, int32_t* count) {
+    if (samples < 0 || n_members < 1 || member < 0 || member >= n_members || !begin || !count) return CR_ERR_INVALID_ARG;
+    const int64_t b = (int64_t)member * samples / n_members, e = (int64_t)(member + 1) * samples / n_members;
+    *begin = (int32_t)b; *count = (int32_t)(e - b);
+    return CR_OK;
+}
+
+int32_t cr_group_create(const int32_t* device_ids, int32_t n_devices, CrGroup** out) {
+    if (!out) return gfail(nullptr, CR_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (!device_ids || n_devices < 1) return gfail(nullptr, CR_ERR_INVALID_ARG, "device list is empty");
+    for (int i = 0; i < n_devices; i++) for (int j = 0; j < i; j++)
+        if (device_ids[i] == device_ids[j]) return gfail(nullptr, CR_ERR_INVALID_ARG, "a device appears twice in the list");
+    CrGroup* g = new CrGroup();
+    g->world = n_devices; g->first = 0;
+    g->members.assign((size_t)n_devices, nullptr);
+    g->partial.resize((size_t)n_devices);
+    for (int i = 0; i < n_devices; i++) {
+        int32_t rc = cr_create(device_ids[i], &g->members[(size_t)i]);
+        if (rc != CR_OK) { g_group_create_error = g_create_error; group_free(g); return rc; }
+    }
+    const bool force = getenv("CRUCIBLE_GROUP_FORCE_RCCL") != nullptr;   // tests: exercise the collective on one device
+    if (n_devices > 1 || force) {
+        RcclApi& api = rccl_api();
+        if (!api.lib) { g_group_create_error = api.error; group_free(g); return CR_ERR_UNSUPPORTED; }
+        g->comms.assign((size_t)n_devices, nullptr);
+        ncclResult_t r = api.CommInitAll(g->comms.data(), n_devices, device_ids);
+        if (r != ncclSuccess) { g_group_create_error = std::string("ncclCommInitAll: ") + api.GetErrorString(r); g->comms.clear(); group_free(g); return CR_ERR_HIP; }
+    }
+    (void)hipSetDevice(g->members[0]->device);
+    if (hipEventCreate(&g->ev0) != hipSuccess || hipEventCreate(&g->ev1) != hipSuccess) { g_group_create_error = "hipEventCreate failed"; group_free(g); return CR_ERR_HIP; }
+    *out = g;
+    return CR_OK;
+}
+
+int32_t cr_group_unique_id(uint8_t id[CR_GROUP_ID_BYTES]) {
+    static_assert(CR_GROUP_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    if (!id) return gfail(nullptr, CR_ERR_INVALID_ARG, "id is null");
+    RcclApi& api = rccl_api();
+    if (!api.lib) return gfail(nullptr, CR_ERR_UNSUPPORTED, api.error);
+    ncclUniqueId u;
+    ncclResult_t r = api.GetUniqueId(&u);
+    if (r != ncclSuccess) return gfail(nullptr, CR_ERR_HIP, std::string("ncclGetUniqueId: ") + api.GetErrorString(r));
+    memcpy(id, u.internal, CR_GROUP_ID_BYTES);
+    return CR_OK;
+}
+
+int32_t cr_group_create_rank(int32_t device_id, int32_t rank, int32_t world_size, const uint8_t id[CR_GROUP_ID_BYTES], CrGroup** out) {
+    if (!out) return gfail(nullptr, CR_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (world_size < 1 || rank < 0 || rank >= world_size) return gfail(nullptr, CR_ERR_INVALID_ARG, "rank outside [0, world_size)");
+    if (world_size > 1 && !id) return gfail(nullptr, CR_ERR_INVALID_ARG, "id is null");
+    CrGroup* g = new CrGroup();
+    g->world = world_size; g->first = rank;
+    g->members.assign(1, nullptr);
+    g->partial.resize(1);
+    int32_t rc = cr_create(device_id, &g->members[0]);
+    if (rc != CR_OK) { g_group_create_error = g_create_error; group_free(g); return rc; }
+    const bool force = getenv("CRUCIBLE_GROUP_FORCE_RCCL") != nullptr && id;
+    if (world_size > 1 || force) {
+        RcclApi& api = rccl_api();
+        if (!api.lib) { g_group_create_error = api.error; group_free(g); return CR_ERR_UNSUPPORTED; }
+        ncclUniqueId u;
+        memcpy(u.internal, id, CR_GROUP_ID_BYTES);
+        g->comms.assign(1, nullptr);
+        (void)hipSetDevice(device_id);
+        ncclResult_t r = api.CommInitRank(&g->comms[0], world_size, u, rank);
+        if (r != ncclSuccess) { g_group_create_error = std::string("ncclCommInitRank: ") + api.GetErrorString(r); g->comms.clear(); group_free(g); return CR_ERR_HIP; }
+    }
+    (void)hipSetDevice(device_id);
+    if (hipEventCreate(&g->ev0) != hipSuccess || hipEventCreate(&g->ev1) != hipSuccess) { g_group_create_error = "hipEventCreate failed"; group_free(g); return CR_ERR_HIP; }
+    *out = g;
+    return CR_OK;
+}
+
+void cr_group_destroy(CrGroup* g) { group_free(g); }
+int32_t cr_group_local_size(CrGroup* g) { return g ? (int32_t)g->members.size() : 0; }
+int32_t cr_group_size(CrGroup* g) { return g ? g->world : 0; }
+int32_t cr_group_rank(CrGroup* g) { return g ? g->first : -1; }
+CrHandle* cr_group_handle(CrGroup* g, int32_t i) { return (g && i >= 0 && i < (int32_t)g->members.size()) ? g->members[(size_t)i] : nullptr; }
+const char* cr_group_last_error(CrGroup* g) { return g ? g->error.c_str() : g_group_create_error.c_str(); }
+
+int32_t cr_group_upload_scene(CrGroup* g, const CrSceneDesc* scene) {
+    if (!g) return CR_ERR_INVALID_ARG;
+    for (CrHandle* h : g->members) {
+        int32_t rc = cr_upload_scene(h, scene);
+        if (rc != CR_OK) return gfail(g, rc, h->error);
+    }
+    return CR_OK;
+}
+
+int32_t cr_group_render(CrGroup* g, const CrCameraDesc* cam, const CrRenderParams* params, void* d_out, CrGroupStats* stats) {
+    if (!g) return CR_ERR_INVALID_ARG;
+    if (!cam || !params) return gfail(g, CR_ERR_INVALID_ARG, "null camera or params");
+    const bool root_here = g->first == 0;
+    if (root_here && !d_out) return gfail(g, CR_ERR_INVALID_ARG, "the root member needs an output buffer");
+    const size_t n = (size_t)cam->image_width * (size_t)cam->image_height * 3;
+    const bool f64 = params->real_type == CR_REAL_F64;
+    const size_t bytes = n * (f64 ? sizeof(double) : sizeof(float));
+    const bool collective = !g->comms.empty();
+    const int local = (int)g->members.size();
+    std::vector<int32_t> counts((size_t)local, 0);
+    // 1. every local member renders its shard, asynchronously on its own stream
+    for (int i = 0; i < local; i++) {
+        CrHandle* h = g->members[(size_t)i];
+        CrRenderParams p = *params;
+        if (cr_group_shard(params->samples, g->first + i, g->world, &p.sample_begin, &p.sample_count) != CR_OK)
+            return gfail(g, CR_ERR_INVALID_ARG, "samples must be >= 0");
+        counts[(size_t)i] = p.sample_count;
+        void* dst = d_out;
+        if (g->world > 1 || collective) {
+            p.output_sum = 1;
+            GHIP_TRY(g, hipSetDevice(h->device));
+            GHIP_TRY(g, g->partial[(size_t)i].ensure(bytes));
+            dst = g->partial[(size_t)i].p;
+        } else p.output_sum = 0;   // one member, no collective: exactly cr_render_device
+        int32_t rc = cr_render_device(h, cam, &p, dst, nullptr);
+        if (rc != CR_OK) return gfail(g, rc, h->error);
+    }
+    // 2. one reduce of the sums to the root, then the divide there
+    if (g->world > 1 || collective) {
+        CrHandle* root = g->members[0];
+        if (root_here) { GHIP_TRY(g, hipSetDevice(root->device)); GHIP_TRY(g, hipEventRecord(g->ev0, root->stream)); }
+        if (collective) {
+            RcclApi& api = rccl_api();
+            const ncclDataType_t dt = f64 ? ncclDouble : ncclFloat;
+            NCCL_TRY(g, api, api.GroupStart());
+            for (int i = 0; i < local; i++) {
+                CrHandle* h = g->members[(size_t)i];
+                GHIP_TRY(g, hipSetDevice(h->device));
+                void* buf = g->partial[(size_t)i].p;   // in place on the root
+                NCCL_TRY(g, api, api.Reduce(buf, buf, n, dt, ncclSum, 0, g->comms[(size_t)i], h->stream));
+            }
+            NCCL_TRY(g, api, api.GroupEnd());
+        }
+        if (root_here) {
+            GHIP_TRY(g, hipSetDevice(root->device));
+            const unsigned grid = (unsigned)((n + 255) / 256);
+            if (f64) hipLaunchKernelGGL((group_mean_kernel<double>), dim3(grid), dim3(256), 0, root->stream, (const double*)g->partial[0].p, (double*)d_out, n, (double)params->samples);
+            else hipLaunchKernelGGL((group_mean_kernel<float>), dim3(grid), dim3(256), 0, root->stream, (const float*)g->partial[0].p, (float*)d_out, n, (float)params->samples);
+            GHIP_TRY(g, hipGetLastError());
+            GHIP_TRY(g, hipEventRecord(g->ev1, root->stream));
+        }
+    }
+    // 3. wait for every local stream
+    for (CrHandle* h : g->members) { GHIP_TRY(g, hipSetDevice(h->device)); GHIP_TRY(g, hipStreamSynchronize(h->stream)); }
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->members = g->world; stats->used_rccl = collective ? 1 : 0;
+        const int64_t npix = (int64_t)cam->image_width * cam->image_height;
+        for (int i = 0; i < local; i++) {
+            CrStats s;
+            int32_t rc = member_stats(g->members[(size_t)i], npix * counts[(size_t)i], &s);
+            if (rc != CR_OK) return gfail(g, rc, g->members[(size_t)i]->error);
+            stats->render.samples += s.samples; stats->render.segments += s.segments; stats->render.node_tests += s.node_tests;
+            stats->render.prim_tests += s.prim_tests; stats->render.texel_fetches += s.texel_fetches;
+            stats->render.kernel_ms = std::max(stats->render.kernel_ms, s.kernel_ms);
+            stats->render.upload_ms = std::max(stats->render.upload_ms, s.upload_ms);
+        }
+        if (root_here && (g->world > 1 || collective)) {
+            float ms = 0;
+            GHIP_TRY(g, hipSetDevice(g->members[0]->device));
+            GHIP_TRY(g, hipEventElapsedTime(&ms, g->ev0, g->ev1));
+            stats->reduce_ms = ms;
+        }
+    }
+    return CR_OK;
+}
 
 }   // extern "C"

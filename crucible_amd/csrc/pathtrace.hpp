@@ -213,6 +213,7 @@ template <typename real> struct KernelArgs {
     const ImageRef* images;
     const uint32_t* texels;
     const Key<real>* keys;
+    const Key<real>* cam_keys;   // this launch's camera keyframes (look_from keys, then look_at keys)
     int32_t n_entries, n_prims, n_mats, n_texs;
     int32_t lds_entries;      // entries staged in LDS (all of them, or the top levels of a large tree)
     int32_t sky_kind, sky_image;
@@ -242,8 +243,14 @@ template <typename real> struct KernelArgs {
 };
 
 // ------------------------------------------------------------------ timeline (timeline/mod.rs:233-263)
-template <typename real> CR_HD void timeline_eval(const Key<real>* keys, int n, real t, real& x, real& y, real& z, real& w) {
+// combine_and_compute = S * T * (0,0,0,1): T's last column is the initial position plus every active translate
+// value, added in list order; S is the LAST active scale transform (:249-255) -- the initial one (sphere:
+// diag(1,1,1,r); others: diag(s,s,s,s), s = 1), a ScaleR key (radius), or a ScaleX / ScaleY / ScaleZ key
+// (transform_builder.rs:101-346).  x,y,z come back as T's column, w as the scale value, *skind as the channel of
+// the scale key that won (-1: the initial scale).
+template <typename real> CR_HD void timeline_eval(const Key<real>* keys, int n, real t, real& x, real& y, real& z, real& w, int32_t* skind = nullptr) {
     x = real(0) + x; y = real(0) + y; z = real(0) + z;   // identity * initial translate
+    int32_t sk = -1;
     for (int i = 0; i < n; i++) {
         Key<real> k = keys[i];
         bool active = (t > k.t1) || (k.t0 <= t && t <= k.t1);   // is_less(t) || contains(t)
@@ -252,10 +259,29 @@ template <typename real> CR_HD void timeline_eval(const Key<real>* keys, int n, 
         if (k.channel <= 2) {
             real val = k.interp ? k.a * s : k.a;
             if (k.channel == 0) x = x + val; else if (k.channel == 1) y = y + val; else z = z + val;
-        } else if (k.channel == 3) {
+        } else {
             w = k.interp ? k.a + (k.b - k.a) * s : k.a;
+            sk = k.channel;
         }
     }
+    if (skind) *skind = sk;
+}
+// S * (x, y, z, 1) for a non-sphere point (a triangle vertex; the 4th component is dropped, triangle.rs:95-97).
+// ScaleX is diag(v,1,1,1) and ScaleZ diag(1,1,v,1); ScaleY writes v into row 1, column 0 and leaves the diagonal
+// at 1 (transform_builder.rs:228-246), so it shears y by v*x.  Rows of S that hold only a unit diagonal return the
+// coordinate unchanged (1*y plus zeros).
+template <typename real> CR_HD V3<real> scale_point(int32_t skind, real v, real x, real y, real z) {
+    if (skind == 4) return mk<real>(v * x, y, z);
+    if (skind == 5) return mk<real>(x, v * x + y, z);
+    if (skind == 6) return mk<real>(x, y, v * z);
+    return mk<real>(v * x, v * y, v * z);   // build_other_scaler, matrix_builder.rs:63-86
+}
+// One vertex timeline of a triangle (a_timeline / b_timeline / c_timeline share their keys, scene_animator.rs).
+template <typename real> CR_HD V3<real> timeline_vertex(const Key<real>* keys, int n, real t, V3<real> p) {
+    real w = real(1);
+    int32_t sk;
+    timeline_eval(keys, n, t, p.x, p.y, p.z, w, &sk);
+    return scale_point(sk, w, p.x, p.y, p.z);
 }
 
 // ------------------------------------------------------------------ camera (rendering_compute.rs)
@@ -428,8 +454,8 @@ CR_D void camera_ray(const KernelArgs<real>& A, uint32_t pix_i, uint32_t pix_j, 
     if (ANIM && cam.animated) {
         real fx = cam.from.x, fy = cam.from.y, fz = cam.from.z, fw = real(1);
         real ax = cam.at.x, ay = cam.at.y, az = cam.at.z, aw = real(1);
-        timeline_eval(A.keys + cam.from_key_first, cam.from_key_count, ts, fx, fy, fz, fw);
-        timeline_eval(A.keys + cam.at_key_first, cam.at_key_count, ts, ax, ay, az, aw);
+        timeline_eval(A.cam_keys + cam.from_key_first, cam.from_key_count, ts, fx, fy, fz, fw);
+        timeline_eval(A.cam_keys + cam.at_key_first, cam.at_key_count, ts, ax, ay, az, aw);
         f = camera_frame(cam, mk<real>(fw * fx, fw * fy, fw * fz), mk<real>(aw * ax, aw * ay, aw * az));
     } else {
         f.from = cam.from; f.p00 = cam.p00; f.pdu = cam.pdu; f.pdv = cam.pdv; f.ddu = cam.ddu; f.ddv = cam.ddv;
@@ -467,7 +493,7 @@ CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<re
         int32_t leaf_tex = -1;
         if (m.kind == 0 && m.tex >= 0) {   // only image textures read u,v
             int ti = m.tex;
-            for (int guard = 0; guard < 32 && texs[ti].kind == 1; guard++) {   // checker_texture.rs:38-51
+            for (int guard = 0; guard < 32 && texs[ti].kind == 1; guard++) {   // checker_texture.rs:38-51; <= CR_MAX_CHECKER_DEPTH levels by upload
                 const Tex<real>& tx = texs[ti];
                 int32_t s = (int32_t)((uint32_t)as_i32(r_floor(tx.inv_scale * loc.x)) + (uint32_t)as_i32(r_floor(tx.inv_scale * loc.y)) +
                                       (uint32_t)as_i32(r_floor(tx.inv_scale * loc.z)));
@@ -491,10 +517,9 @@ CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<re
         } else {
             V3<real> a = mk<real>(p.g[0], p.g[1], p.g[2]), b = mk<real>(p.g[3], p.g[4], p.g[5]), c = mk<real>(p.g[6], p.g[7], p.g[8]);
             if (ANIM && p.key_count) {
-                real w = real(1);
-                timeline_eval(A.keys + p.key_first, p.key_count, rtime, a.x, a.y, a.z, w); a = scale(w, a); w = real(1);
-                timeline_eval(A.keys + p.key_first, p.key_count, rtime, b.x, b.y, b.z, w); b = scale(w, b); w = real(1);
-                timeline_eval(A.keys + p.key_first, p.key_count, rtime, c.x, c.y, c.z, w); c = scale(w, c);
+                a = timeline_vertex(A.keys + p.key_first, p.key_count, rtime, a);
+                b = timeline_vertex(A.keys + p.key_first, p.key_count, rtime, b);
+                c = timeline_vertex(A.keys + p.key_first, p.key_count, rtime, c);
             }
             n = unit(cross(sub(b, a), sub(c, a)));          // safe_new, objects/mod.rs:76
             tu = 0; tv = 0;                                 // triangle.rs:130-131
@@ -689,10 +714,9 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
             } else {
                 V3<real> a = mk<real>(g0, g1, g2), b = mk<real>(g3, p.g[4], p.g[5]), c = mk<real>(p.g[6], p.g[7], p.g[8]);
                 if (ANIM && p.key_count) {
-                    real ws = real(1);
-                    timeline_eval(A.keys + p.key_first, p.key_count, rtime, a.x, a.y, a.z, ws); a = scale(ws, a); ws = real(1);
-                    timeline_eval(A.keys + p.key_first, p.key_count, rtime, b.x, b.y, b.z, ws); b = scale(ws, b); ws = real(1);
-                    timeline_eval(A.keys + p.key_first, p.key_count, rtime, c.x, c.y, c.z, ws); c = scale(ws, c);
+                    a = timeline_vertex(A.keys + p.key_first, p.key_count, rtime, a);
+                    b = timeline_vertex(A.keys + p.key_first, p.key_count, rtime, b);
+                    c = timeline_vertex(A.keys + p.key_first, p.key_count, rtime, c);
                 }
                 h = triangle_t(a, b, c, ro, rd, tmin, w.best_t, t);
             }
@@ -886,7 +910,7 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
         } else if (finished) {
             acc_r += col.x; acc_g += col.y; acc_b += col.z;
             sample++;
-            if (sample == A.sample_end) {
+            if (sample >= A.sample_end) {
                 size_t o = ((size_t)pix_j * (size_t)cam.W + pix_i) * 3;
                 if (A.output_sum) { A.out[o] = acc_r; A.out[o + 1] = acc_g; A.out[o + 2] = acc_b; }
                 else {

@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(1024) queue_kernel(const KernelArgs<real> A) {
             if (finished) {   // average_samples (ray_casting.rs:154-173): samples are added in draw order
                 acc_r += col.x; acc_g += col.y; acc_b += col.z;
                 sample++; finished = false;
-                if (sample == A.sample_end) {
+                if (sample >= A.sample_end) {
                     const size_t o = ((size_t)pix_j * (size_t)cam.W + pix_i) * 3;
                     if (A.output_sum) { A.out[o] = acc_r; A.out[o + 1] = acc_g; A.out[o + 2] = acc_b; }
                     else {

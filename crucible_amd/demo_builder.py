@@ -141,6 +141,20 @@ def load_teapot(threads=1, image_width=400, samples=200, sky=None):
     return sc
 
 
+def scaled_teapot(threads=1, image_width=400, samples=200, sky=None):
+    """The teapot with every non-sphere scale builder on it (scene_animator.rs:38-229) plus a translation: what
+    demo_movies::moving_teapot (demo_movies.rs:125) is after -- it calls scale_r on the mesh, which the reference's
+    own type check rejects.  Keys fall inside the first frames' shutter intervals so a still image shows them."""
+    from .scene import LERP, LOCAL, NERP
+    sc = load_teapot(threads, image_width, samples, sky)
+    sc.scale_x(1.4, 0.012, LERP, "teapot")
+    sc.scale_y(0.25, 0.016, NERP, "teapot")
+    sc.translate_point((0.0, 0.4, 0.3), 0.02, LERP, LOCAL, "teapot")
+    sc.scale_all_uniform(1.2, 0.05, LERP, "teapot")
+    sc.scale_z(0.7, 0.09, LERP, "teapot")
+    return sc
+
+
 def earth(threads=1, image_width=400, samples=500, image=None):
     """demo_images.rs:202-221; `image` replaces earthmap.jpg with an in-memory RTWImage."""
     sc = Scene.new_image(16.0 / 9.0, image_width, 24, 180.0, threads)

@@ -51,7 +51,7 @@ enum class TransformSpace { World, Local };     // timeline/mod.rs:108-111
 
 class TransformTimeline {
     struct Tf { int channel; int ttype; double t0, t1; int interp; double a, b; int end_kind; double end_v[3]; };
-    enum { TX = 0, TY = 1, TZ = 2, SR = 3, OMNI = 9, END_AXIS = 0, END_INIT = 1 };
+    enum { TX = 0, TY = 1, TZ = 2, SR = 3, SX = 4, SY = 5, SZ = 6, OMNI = 9, END_AXIS = 0, END_INIT = 1 };
     std::vector<Tf> scale_, translate_;
 
     static const Tf* most_recent(const std::vector<Tf>& l, double t, int ttype) {   // helper_functions.rs:41-140
@@ -97,6 +97,24 @@ public:
                                               : Tf{CR_KEY_RADIUS, SR, keyframe, keyframe, CR_KEY_NERP, r, 0.0, END_AXIS, {r, 0, 0}};
         scale_.push_back(tf);
         std::stable_sort(scale_.begin(), scale_.end(), [](const Tf& a, const Tf& b) { return a.t0 < b.t0; });
+    }
+    // scale_x / scale_y / scale_z (transform_builder.rs:101-346) -> CR_KEY_SCALE_X/Y/Z; which matrix slot each writes
+    // (ScaleY: row 1, column 0) is applied where the keys are evaluated (pathtrace.hpp scale_point)
+    void scale_axis(int ttype, double x, double keyframe, InterpolationType it) {
+        if (!(keyframe >= 0.0)) throw std::invalid_argument("Cannot add a keyframe before the animation start.");
+        const Tf* prev = most_recent(scale_, keyframe, ttype);
+        if (!prev) throw std::runtime_error("Missing transform data! Tried to scale an axis but could not find a previous scale reference!");
+        double prev_time = std::max(prev->t1, 0.0), start = prev->end_v[0];
+        Tf tf = it == InterpolationType::LERP ? Tf{ttype, ttype, prev_time, keyframe, CR_KEY_LERP, start, x, END_AXIS, {x, 0, 0}}
+                                              : Tf{ttype, ttype, keyframe, keyframe, CR_KEY_NERP, x, 0.0, END_AXIS, {x, 0, 0}};
+        scale_.push_back(tf);
+        std::stable_sort(scale_.begin(), scale_.end(), [](const Tf& a, const Tf& b) { return a.t0 < b.t0; });
+    }
+    void scale_x(double x, double k, InterpolationType it) { scale_axis(SX, x, k, it); }
+    void scale_y(double y, double k, InterpolationType it) { scale_axis(SY, y, k, it); }
+    void scale_z(double z, double k, InterpolationType it) { scale_axis(SZ, z, k, it); }
+    void scale_point(Point3 p, double k, InterpolationType it) {   // transform_builder.rs:729-733
+        scale_x(p.x, k, it); scale_y(p.y, k, it); scale_z(p.z, k, it);
     }
     std::vector<CrKeyframe> keyframes() const {   // translate list order, then scale list order
         std::vector<CrKeyframe> out;
@@ -393,6 +411,24 @@ public:
         size_t id = lookup(alias, {"Camera", "TriangleMesh", "Triangle"});
         for (Hittables& e : elements) if (e.id == id) e.timeline.scale_sphere(r, k, it);
     }
+    // ScaleX / ScaleY / ScaleZ / ScaleAll: invalid on spheres, applied to the alias's triangles (:38-229)
+    void scale_x(double x, double k, InterpolationType it, const std::string& alias) {
+        size_t id = lookup(alias, {"Sphere"});
+        for (Hittables& e : elements) if (e.id == id && e.kind == CR_PRIM_TRIANGLE) e.timeline.scale_x(x, k, it);
+    }
+    void scale_y(double y, double k, InterpolationType it, const std::string& alias) {
+        size_t id = lookup(alias, {"Sphere"});
+        for (Hittables& e : elements) if (e.id == id && e.kind == CR_PRIM_TRIANGLE) e.timeline.scale_y(y, k, it);
+    }
+    void scale_z(double z, double k, InterpolationType it, const std::string& alias) {
+        size_t id = lookup(alias, {"Sphere"});
+        for (Hittables& e : elements) if (e.id == id && e.kind == CR_PRIM_TRIANGLE) e.timeline.scale_z(z, k, it);
+    }
+    void scale_point(Point3 p, double k, InterpolationType it, const std::string& alias) {
+        size_t id = lookup(alias, {"Sphere"});
+        for (Hittables& e : elements) if (e.id == id && e.kind == CR_PRIM_TRIANGLE) e.timeline.scale_point(p, k, it);
+    }
+    void scale_all_uniform(double v, double k, InterpolationType it, const std::string& alias) { scale_point(Point3{v, v, v}, k, it, alias); }   // :217-219
     void cam_translate_point(Point3 p, double k, InterpolationType it, TransformSpace sp, const std::string& which) {   // :532-556
         if (which != "from" && which != "at") throw std::invalid_argument("alias must be 'from' or 'at'");
         (which == "from" ? scene_cam.look_from_tl : scene_cam.look_at_tl).translate_point(p, k, it, sp);
@@ -587,6 +623,19 @@ inline Scene load_teapot(size_t threads, uint32_t image_width = 400, uint32_t sa
     book1_camera(sc.scene_cam, samples, Point3{13, 10, 3});
     sc.load_asset("teapot.obj", "teapot", 0.5, Point3{0, 0, 0}, Materials::metal(Color(0.8, 0.3, 0.5), 0.05));
     sc.add_element(Hittables::sphere(Point3{0, -1000, 0}, 1000.0, checker_ground()), "ground");
+    return sc;
+}
+
+// The teapot with every non-sphere scale builder on it (scene_animator.rs:38-229) plus a translation: what
+// demo_movies::moving_teapot (demo_movies.rs:125) is after -- it calls scale_r on the mesh, which the reference's own
+// type check rejects.  Keys fall inside the first frames' shutter intervals so a still image shows them.
+inline Scene scaled_teapot(size_t threads, uint32_t image_width = 400, uint32_t samples = 200) {
+    Scene sc = load_teapot(threads, image_width, samples);
+    sc.scale_x(1.4, 0.012, InterpolationType::LERP, "teapot");
+    sc.scale_y(0.25, 0.016, InterpolationType::NERP, "teapot");
+    sc.translate_point(Point3{0.0, 0.4, 0.3}, 0.02, InterpolationType::LERP, TransformSpace::Local, "teapot");
+    sc.scale_all_uniform(1.2, 0.05, InterpolationType::LERP, "teapot");
+    sc.scale_z(0.7, 0.09, InterpolationType::LERP, "teapot");
     return sc;
 }
 

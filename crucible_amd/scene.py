@@ -431,6 +431,28 @@ class Scene:
             if e.id == oid:
                 e.timeline.scale_sphere(r, keyframe, it)
 
+    def _scale_non_sphere(self, method, value, keyframe, it, alias, what):
+        # scene_animator.rs:38-229: ScaleX/Y/Z/All type-check against Sphere only and touch Triangles
+        oid = self._lookup(alias, invalid=("Sphere",))
+        for e in self.elements:
+            if e.id == oid and isinstance(e, Triangle):
+                getattr(e.timeline, method)(value, keyframe, it)
+
+    def scale_x(self, x, keyframe, it, alias):
+        self._scale_non_sphere("scale_x", x, keyframe, it, alias, "ScaleX")
+
+    def scale_y(self, y, keyframe, it, alias):
+        self._scale_non_sphere("scale_y", y, keyframe, it, alias, "ScaleY")
+
+    def scale_z(self, z, keyframe, it, alias):
+        self._scale_non_sphere("scale_z", z, keyframe, it, alias, "ScaleZ")
+
+    def scale_point(self, p, keyframe, it, alias):
+        self._scale_non_sphere("scale_point", tuple(float(c) for c in p), keyframe, it, alias, "ScaleAll")
+
+    def scale_all_uniform(self, v, keyframe, it, alias):   # scene_animator.rs:217-219
+        self.scale_point((v, v, v), keyframe, it, alias)
+
     def cam_translate_point(self, p, keyframe, it, space, which):
         tl = self.scene_cam.look_from_tl if which == "from" else self.scene_cam.look_at_tl
         tl.translate_point(p, keyframe, it, space)

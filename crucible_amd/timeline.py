@@ -6,8 +6,9 @@ builders `translate_{x,y,z,point}` / `scale_sphere`
 closures; only three closure shapes ever appear on the translate / radius
 channels (`move |_t| c`, `move |t| x * t`, `move |t| s + (r - s) * t`), so each
 Transform flattens to one CrKeyframe (include/crucible_hip.h).  The per-axis
-x/y/z scale builders are not mirrored: they are outside the render path's
-scope.
+scale builders `scale_{x,y,z,point}` (transform_builder.rs:101-346,729) flatten to
+the CR_KEY_SCALE_* channels; which matrix slot each writes (ScaleY: row 1,
+column 0) is applied where the keys are evaluated (pathtrace.hpp scale_point).
 """
 from dataclasses import dataclass
 
@@ -111,6 +112,40 @@ class TransformTimeline:
             tf = _Transform(A.CR_KEY_RADIUS, "ScaleR", keyframe, keyframe, A.CR_KEY_NERP, r, 0.0, ("ScaleR", r))
         self.scale.append(tf)
         self.scale.sort(key=lambda t: t.t0)
+
+    def _scale_axis(self, axis, x, keyframe, interp):
+        # scale_x / scale_y / scale_z, transform_builder.rs:101-346: the previous ScaleX|Y|Z (or the initial Omni)
+        # transform gives the start value and, for LERP, the start time
+        assert keyframe >= 0.0, "Cannot add a keyframe before the animation start."
+        ttype = ("ScaleX", "ScaleY", "ScaleZ")[axis]
+        channel = (A.CR_KEY_SCALE_X, A.CR_KEY_SCALE_Y, A.CR_KEY_SCALE_Z)[axis]
+        x, keyframe = float(x), float(keyframe)
+        prev = self._most_recent(self.scale, keyframe, ttype)
+        if prev is None:
+            raise ValueError(f"Missing transform data! Tried to scale {'xyz'[axis]} but could not find a previous scale reference!")
+        prev_end = prev.end
+        prev_time = max(prev.t1, 0.0)
+        if interp == LERP:
+            start = prev_end[1]   # ScaleX(start) | InitScale(start)
+            tf = _Transform(channel, ttype, prev_time, keyframe, A.CR_KEY_LERP, start, x, (ttype, x))
+        else:
+            tf = _Transform(channel, ttype, keyframe, keyframe, A.CR_KEY_NERP, x, 0.0, (ttype, x))
+        self.scale.append(tf)
+        self.scale.sort(key=lambda t: t.t0)
+
+    def scale_x(self, x, keyframe, interp):
+        self._scale_axis(0, x, keyframe, interp)
+
+    def scale_y(self, y, keyframe, interp):
+        self._scale_axis(1, y, keyframe, interp)
+
+    def scale_z(self, z, keyframe, interp):
+        self._scale_axis(2, z, keyframe, interp)
+
+    def scale_point(self, p, keyframe, interp):   # transform_builder.rs:729-733
+        self.scale_x(p[0], keyframe, interp)
+        self.scale_y(p[1], keyframe, interp)
+        self.scale_z(p[2], keyframe, interp)
 
     def is_static(self):
         return len(self.scale) == 1 and len(self.translate) == 1

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CR_ABI_VERSION 1
+#define CR_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define CR_API __attribute__((visibility("default")))
@@ -93,6 +93,9 @@ typedef struct CrMaterial {
 
 /* ---- textures: Textures::{SolidColor,CheckerTexture,ImageTexture} (src/textures/mod.rs:12-17) ---- */
 enum { CR_TEX_SOLID = 0, CR_TEX_CHECKER = 1, CR_TEX_IMAGE = 2 };
+/* Checker textures may nest (checker_texture.rs:12-13 hold arbitrary Arc<Textures>); cr_upload_scene returns
+ * CR_ERR_UNSUPPORTED for a chain of more than this many checker levels. */
+#define CR_MAX_CHECKER_DEPTH 32
 
 typedef struct CrTexture {
     int32_t kind;
@@ -125,10 +128,20 @@ enum { CR_SKY_DEFAULT = 0, CR_SKY_SPHERICAL = 1 };
  *                   value = a (NERP) | a * s (LERP), s = clamp((t-t0)/(t1-t0),0,1)
  *                   (timeline/mod.rs:90-96, transform_builder.rs `move |t| x * t`).
  *                   Active values are added in array order (timeline/mod.rs:243-246).
- *   channel 3     : sphere radius.  The LAST active key wins (timeline/mod.rs:249-255);
- *                   value = a (NERP) | a + (b - a) * s (LERP).
+ *   channel 3     : sphere radius (scale_sphere, transform_builder.rs:17-96).  Spheres only.
+ *   channel 4,5,6 : ScaleX / ScaleY / ScaleZ of a triangle (scale_x/y/z, scale_point, scale_all_uniform:
+ *                   scene_animator.rs:38-229, transform_builder.rs:101-346,729).  Triangles only.
+ *                   Channels 3..6 are the timeline's `scale` list: the LAST active key in array order wins and
+ *                   replaces the initial scale (timeline/mod.rs:249-255); value v = a (NERP) | a + (b - a) * s
+ *                   (LERP: `start + (x - start) * t`).  A vertex (x,y,z) -- after the translate keys -- becomes
+ *                   ScaleX: (v*x, y, z); ScaleZ: (x, y, v*z); ScaleY: (x, v*x + y, z) -- the reference writes the
+ *                   y factor into row 1, column 0 of the matrix (transform_builder.rs:228-246) and this ABI
+ *                   reproduces that.  scale_point pushes X, Y, Z keys with one interval, so its Z key wins.
+ *                   Keys must arrive in the timeline's list order (translate list, then scale list, each stably
+ *                   sorted by start time as the reference sorts them).
  */
-enum { CR_KEY_TX = 0, CR_KEY_TY = 1, CR_KEY_TZ = 2, CR_KEY_RADIUS = 3 };
+enum { CR_KEY_TX = 0, CR_KEY_TY = 1, CR_KEY_TZ = 2, CR_KEY_RADIUS = 3, CR_KEY_SCALE_X = 4, CR_KEY_SCALE_Y = 5,
+       CR_KEY_SCALE_Z = 6 };
 enum { CR_KEY_NERP = 0, CR_KEY_LERP = 1 };
 
 typedef struct CrKeyframe {
@@ -322,6 +335,63 @@ CR_API int32_t cr_quantize_rgb8(const void* rgb, int32_t real_type, int64_t n_pi
 
 /* Last error text of this handle (NULL handle: last create error). */
 CR_API const char* cr_last_error(CrHandle* h);
+
+/*
+ * ---- several GPUs of one node: samples-per-pixel sharding + one RCCL reduce ----
+ *
+ * Every sample is an independent path (src/camera/ray_casting.rs:82-105) and the random stream is keyed by
+ * (seed, pixel, sample), so member g of G renders sample indices cr_group_shard(samples, g, G) of EVERY pixel as raw
+ * per-pixel sums (the scene is replicated), one ncclReduce(sum, f32 | f64 per real_type, count = W*H*3, root = member 0)
+ * over xGMI adds them, and the root divides by `samples` (average_samples' `/= count`, ray_casting.rs:168-170).  The
+ * union is the 1-GPU sample set; the image differs from the 1-GPU one only by the order of the floating-point adds
+ * (a group of one member is bit-identical to cr_render_device).  This replaces the reference's worker pool
+ * (src/camera/cpu_threading.rs:25-115: `thread_count` OS threads behind one mutex) across devices.
+ *
+ * Two ways to form a group; both end in the same cr_group_render:
+ *   cr_group_create       one process drives n devices (one handle + stream per device, ncclCommInitAll) -- what a
+ *                         Rust host calling this library would use;
+ *   cr_group_create_rank  one process per GPU (torch.distributed.run style): rank 0 obtains cr_group_unique_id and
+ *                         ships its 128 bytes to every rank by any means (ncclCommInitRank).
+ * RCCL (librccl.so.1) is loaded on first use; a group of ONE member never needs it.  Movies shard whole frames
+ * instead (frame f -> member f % G, src/scene/mod.rs:307-316): no collective, drive cr_group_handle(g) directly.
+ */
+typedef struct CrGroup CrGroup;
+#define CR_GROUP_ID_BYTES 128
+
+/* [begin, begin+count) of member `member` among `n_members`: begin = member*samples/n_members (integer division).
+ * The ranges partition [0, samples); with more members than samples some are empty (they contribute zeros).
+ * Pure arithmetic: callable without a GPU. */
+CR_API int32_t cr_group_shard(int32_t samples, int32_t member, int32_t n_members, int32_t* begin, int32_t* count);
+
+CR_API int32_t cr_group_create(const int32_t* device_ids, int32_t n_devices, CrGroup** out);
+CR_API int32_t cr_group_unique_id(uint8_t id[CR_GROUP_ID_BYTES]);
+CR_API int32_t cr_group_create_rank(int32_t device_id, int32_t rank, int32_t world_size,
+                                    const uint8_t id[CR_GROUP_ID_BYTES], CrGroup** out);
+CR_API void cr_group_destroy(CrGroup* g);
+
+/* Members driven by THIS process (n_devices, or 1 in rank mode) / in the whole group / this process's first member. */
+CR_API int32_t cr_group_local_size(CrGroup* g);
+CR_API int32_t cr_group_size(CrGroup* g);
+CR_API int32_t cr_group_rank(CrGroup* g);
+CR_API CrHandle* cr_group_handle(CrGroup* g, int32_t local_member);
+
+/* cr_upload_scene on every local member (the scene is replicated). */
+CR_API int32_t cr_group_upload_scene(CrGroup* g, const CrSceneDesc* scene);
+
+/* Camera::render across the group.  params->sample_begin/sample_count/output_sum are ignored: the group splits
+ * [0, samples) itself and returns the per-pixel MEAN.  d_out_rgb: device buffer of W*H*3 reals on the ROOT member's
+ * device (member 0 = device_ids[0], or rank 0); other ranks may pass NULL.  Every rank of a rank-mode group must
+ * call this with the same arguments (it is a collective).  Synchronous.  stats (may be NULL): counters summed over
+ * the LOCAL members, kernel_ms = the slowest local member's render, reduce_ms in CrGroupStats. */
+typedef struct CrGroupStats {
+    CrStats render;        /* local members: counters summed, kernel_ms = max */
+    double reduce_ms;      /* root-side time of the ncclReduce + the divide, HIP events on the root's stream */
+    int32_t members;       /* whole group */
+    int32_t used_rccl;     /* 0: a one-member group rendered directly */
+} CrGroupStats;
+CR_API int32_t cr_group_render(CrGroup* g, const CrCameraDesc* cam, const CrRenderParams* params, void* d_out_rgb,
+                               CrGroupStats* stats);
+CR_API const char* cr_group_last_error(CrGroup* g);
 
 #ifdef __cplusplus
 }

@@ -247,30 +247,60 @@ static int key_active(const Key* k, real t) {          /* timeline/mod.rs:239 */
     return iv_is_less(iv, t) || iv_contains(iv, t);
 }
 
+/* S * (x, y, z, 1) for a non-sphere timeline; S = the last active scale transform (timeline/mod.rs:249-255):
+ *   skind < 0      the initial build_other_scaler(s): diag(s,s,s,s)             (matrix_builder.rs:63-86)
+ *   CR_KEY_SCALE_X diag(v,1,1,1)                                               (transform_builder.rs:101-179)
+ *   CR_KEY_SCALE_Y identity with v in ROW 1, COLUMN 0: y' = v*x + y            (transform_builder.rs:228-246)
+ *   CR_KEY_SCALE_Z diag(1,1,v,1)                                               (transform_builder.rs:262-340)
+ * nalgebra forms each component as ((S_i0*x + S_i1*y) + S_i2*z) + S_i3*1; rows holding only a unit diagonal
+ * give the coordinate back (1*c plus zero products), which is written as the coordinate itself here. */
+static void scale_apply(int skind, real v, real x, real y, real z, real out[4]) {
+    if (skind == CR_KEY_SCALE_X) { out[0] = v * x; out[1] = y; out[2] = z; out[3] = R(1.0); }
+    else if (skind == CR_KEY_SCALE_Y) { out[0] = x; out[1] = v * x + y; out[2] = z; out[3] = R(1.0); }
+    else if (skind == CR_KEY_SCALE_Z) { out[0] = x; out[1] = y; out[2] = v * z; out[3] = R(1.0); }
+    else { out[0] = v * x; out[1] = v * y; out[2] = v * z; out[3] = v; }
+}
+
 /* TransformTimeline::combine_and_compute, timeline/mod.rs:233-263.  Translation
  * matrices multiply into a sum of offsets, added in list order starting from the
  * initial position (the t=-0.1 Omni transform is always active and first);
  * the scale is the last active scale transform.  is_sphere selects
- * build_sphere_scaler (w = radius, xyz untouched) vs build_other_scaler
- * (s*x, s*y, s*z, s) -- matrix_builder.rs:39-86. */
-static void timeline_eval(const Timeline* tl, real t, int is_sphere, real out[4]) {
+ * build_sphere_scaler (w = radius, xyz untouched) vs the non-sphere scale
+ * matrices of scale_apply.
+ * side: 0 = the value at t; 1 = the left limit at a key start (a key whose t0 equals t counts as not yet
+ * active) -- used by the refit rule only.  tr / sc: which parts to evaluate at this t (the refit rule samples
+ * them independently): the translate part goes to xyz[0..2], the scale part to *w and *skind. */
+static void timeline_parts(const Timeline* tl, real t, int side, real xyz[3], real* w, int* skind) {
     real x = R(0.0) + tl->init[0], y = R(0.0) + tl->init[1], z = R(0.0) + tl->init[2];
-    real w = tl->init[3];
+    real wv = tl->init[3];
+    int sk = -1;
     for (int i = 0; i < tl->n_keys; i++) {
         const Key* k = &tl->keys[i];
-        if (!key_active(k, t)) continue;
+        int active;
+        if (side) {
+            int started = k->t0 < t;
+            active = (t > k->t1) || (started && t <= k->t1);
+        } else active = key_active(k, t);
+        if (!active) continue;
         real s = key_scaled_time(k, t);
         if (k->channel <= CR_KEY_TZ) {
             real val = (k->interp == CR_KEY_LERP) ? k->a * s : k->a;
             if (k->channel == CR_KEY_TX) x = x + val;
             else if (k->channel == CR_KEY_TY) y = y + val;
             else z = z + val;
-        } else if (k->channel == CR_KEY_RADIUS) {
-            w = (k->interp == CR_KEY_LERP) ? k->a + (k->b - k->a) * s : k->a;
+        } else {   /* ScaleR | ScaleX | ScaleY | ScaleZ: `start + (x - start) * t` */
+            wv = (k->interp == CR_KEY_LERP) ? k->a + (k->b - k->a) * s : k->a;
+            sk = k->channel;
         }
     }
-    if (is_sphere) { out[0] = x; out[1] = y; out[2] = z; out[3] = w; }
-    else { out[0] = w * x; out[1] = w * y; out[2] = w * z; out[3] = w; }
+    xyz[0] = x; xyz[1] = y; xyz[2] = z; *w = wv; *skind = sk;
+}
+static void timeline_eval(const Timeline* tl, real t, int is_sphere, real out[4]) {
+    real p[3], w;
+    int sk;
+    timeline_parts(tl, t, 0, p, &w, &sk);
+    if (is_sphere) { out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = w; }
+    else scale_apply(sk, w, p[0], p[1], p[2], out);
 }
 
 /* ------------------------------------------------------------------ scene objects */
@@ -872,45 +902,54 @@ EXPORT Scene* oracle_scene_create(const CrSceneDesc* d) {
  * wrapper's box is aabb_from_boxes of its children.  The reference never recomputes wrapper boxes
  * (bvhwrapper.rs:47-50,102-106), so this mode is pinned by construction only: against the linear list
  * (oracle_use_list) it must give the same closest hits. */
-static void timeline_eval_side(const Timeline* tl, real t, int before_start, int is_sphere, real out[4]) {
-    real x = R(0.0) + tl->init[0], y = R(0.0) + tl->init[1], z = R(0.0) + tl->init[2];
-    real w = tl->init[3];
-    for (int i = 0; i < tl->n_keys; i++) {
-        const Key* k = &tl->keys[i];
-        int started = before_start ? (k->t0 < t) : (k->t0 <= t);
-        int active = (t > k->t1) || (started && t <= k->t1);
-        if (!active) continue;
-        real s = key_scaled_time(k, t);
-        if (k->channel <= CR_KEY_TZ) {
-            real val = (k->interp == CR_KEY_LERP) ? k->a * s : k->a;
-            if (k->channel == CR_KEY_TX) x = x + val;
-            else if (k->channel == CR_KEY_TY) y = y + val;
-            else z = z + val;
-        } else if (k->channel == CR_KEY_RADIUS) {
-            w = (k->interp == CR_KEY_LERP) ? k->a + (k->b - k->a) * s : k->a;
-        }
-    }
-    if (is_sphere) { out[0] = x; out[1] = y; out[2] = z; out[3] = w; }
-    else { out[0] = w * x; out[1] = w * y; out[2] = w * z; out[3] = w; }
-}
-static Aabb prim_box_at(const Hittable* h, real t, int before_start) {
+/* the primitive's box with its translate part taken at (t, side) and its scale part at (ts, side_s) */
+static Aabb prim_box_at2(const Hittable* h, real t, int side, real ts, int side_s) {
+    real p[3], p2[3], w, w2;
+    int sk, sk2;
     if (h->kind == H_SPHERE) {
-        real sp[4];
-        timeline_eval_side(&h->tl, t, before_start, 1, sp);
-        return sphere_bbox(v3(sp[0], sp[1], sp[2]), sp[3]);
+        timeline_parts(&h->tl, t, side, p, &w, &sk);
+        return sphere_bbox(v3(p[0], p[1], p[2]), w);
     }
-    real pa[4], pb[4], pc[4];
-    Timeline tlb = h->tl, tlc = h->tl;
-    tlb.init[0] = h->vb[0]; tlb.init[1] = h->vb[1]; tlb.init[2] = h->vb[2];
-    tlc.init[0] = h->vc[0]; tlc.init[1] = h->vc[1]; tlc.init[2] = h->vc[2];
-    timeline_eval_side(&h->tl, t, before_start, 0, pa);
-    timeline_eval_side(&tlb, t, before_start, 0, pb);
-    timeline_eval_side(&tlc, t, before_start, 0, pc);
-    return triangle_bbox(v3(pa[0], pa[1], pa[2]), v3(pb[0], pb[1], pb[2]), v3(pc[0], pc[1], pc[2]));
+    Timeline tl[3] = {h->tl, h->tl, h->tl};
+    tl[1].init[0] = h->vb[0]; tl[1].init[1] = h->vb[1]; tl[1].init[2] = h->vb[2];
+    tl[2].init[0] = h->vc[0]; tl[2].init[1] = h->vc[1]; tl[2].init[2] = h->vc[2];
+    Vec3 v[3];
+    for (int j = 0; j < 3; j++) {
+        real o[4];
+        timeline_parts(&tl[j], t, side, p, &w, &sk);
+        timeline_parts(&tl[j], ts, side_s, p2, &w2, &sk2);
+        scale_apply(sk2, w2, p[0], p[1], p[2], o);
+        v[j] = v3(o[0], o[1], o[2]);
+    }
+    return triangle_bbox(v[0], v[1], v[2]);
+}
+static Aabb prim_box_at(const Hittable* h, real t, int before_start) { return prim_box_at2(h, t, before_start, t, before_start); }
+/* sample i of the refit rule: 0 = ta, 1 = tb, then per key its start (active / not yet active) and its end */
+static int refit_sample(const Hittable* h, real ta, real tb, int i, real* t, int* side) {
+    *side = 0;
+    if (i == 0) { *t = ta; return 1; }
+    if (i == 1) { *t = tb; return 1; }
+    const Key* k = &h->tl.keys[(i - 2) / 3];
+    int which = (i - 2) % 3;
+    if (which < 2) { *t = k->t0; *side = which == 1; return ta < k->t0 && k->t0 <= tb; }
+    *t = k->t1;
+    return ta < k->t1 && k->t1 < tb;
 }
 static Aabb prim_box_over(const Hittable* h, real ta, real tb) {
     Aabb b = prim_box_at(h, ta, 0);
     if (h->tl.n_keys == 0) return b;
+    int scaled = 0;
+    for (int i = 0; i < h->tl.n_keys; i++) scaled |= h->tl.keys[i].channel >= CR_KEY_SCALE_X;
+    if (scaled) {   /* translate and scale parts sampled independently, every pair united (refit.hpp) */
+        int n = 2 + 3 * h->tl.n_keys;
+        for (int i = 0; i < n; i++) {
+            real t1, t2; int s1, s2;
+            if (!refit_sample(h, ta, tb, i, &t1, &s1)) continue;
+            for (int j = 0; j < n; j++)
+                if (refit_sample(h, ta, tb, j, &t2, &s2)) b = aabb_from_boxes(b, prim_box_at2(h, t1, s1, t2, s2));
+        }
+        return b;
+    }
     b = aabb_from_boxes(b, prim_box_at(h, tb, 0));
     for (int i = 0; i < h->tl.n_keys; i++) {
         const Key* k = &h->tl.keys[i];

@@ -1,30 +1,112 @@
-// Calibration: issue rate of independent wave64 v_fma_f32 / v_pk_fma-free code at 1..8 waves per SIMD.
+// Calibration: VALU issue rates on this chip, in shader cycles (s_memtime), per instruction kind and per number of
+// resident waves per SIMD.  Every kernel runs 8 independent dependency chains of one instruction per lane, so a single
+// wave already has 8 instructions in flight; the clock is read inside the kernel, so DVFS does not enter the result.
+//   hipcc --offload-arch=gfx950 -O3 -o valu_peak valu_peak.hip && ./valu_peak
+// Output: cycles per wave64 instruction per SIMD (1 / wave-instr per SIMD-cycle); the guide's figure for v_fma_f32 is 2.
 #include <hip/hip_runtime.h>
 #include <cstdio>
-__global__ void __launch_bounds__(1024) fma_loop(float* out, int iters) {
-    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+#include <cstring>
+#include <vector>
+
+#define CHAIN8(OP)                                                                                              \
+    OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+
+enum Kind { FMA_F32, PK_FMA_F32, ADD_F32, MAX_F32, MAX3_F32, CNDMASK, ADD_U32, ADD_F64, MUL_F64, FMA_F64, MAX_F64, RCP_F64, SQRT_F32, N_KINDS };
+static const char* kind_name[N_KINDS] = {"v_fma_f32", "v_pk_fma_f32", "v_add_f32", "v_max_f32", "v_max3_f32", "v_cndmask_b32", "v_add_u32",
+                                         "v_add_f64", "v_mul_f64", "v_fma_f64", "v_max_f64", "v_rcp_f64", "v_sqrt_f32"};
+
+template <int KIND>
+__global__ void __launch_bounds__(256) loop_kernel(unsigned long long* cycles, float* sink, int iters) {
+    float f[8]; double d[8]; unsigned u[8];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p[8];
+    for (int i = 0; i < 8; i++) { f[i] = threadIdx.x + i; d[i] = threadIdx.x + i + 0.5; u[i] = threadIdx.x + i; p[i] = f2{f[i], f[i] + 1}; }
     const float b = 1.000001f, c = 0.5f;
-    for (int i = 0; i < iters; i++) {
-        a0 = __builtin_fmaf(a0, b, c); a1 = __builtin_fmaf(a1, b, c); a2 = __builtin_fmaf(a2, b, c); a3 = __builtin_fmaf(a3, b, c);
-        a4 = __builtin_fmaf(a4, b, c); a5 = __builtin_fmaf(a5, b, c); a6 = __builtin_fmaf(a6, b, c); a7 = __builtin_fmaf(a7, b, c);
+    const double bd = 1.000001, cd = 0.5;
+    const f2 bp = {b, b}, cp = {c, c};
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; it++) {
+#define OP_FMA_F32(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(b), "v"(c));
+#define OP_PK(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(bp), "v"(cp));
+#define OP_ADD_F32(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[i]) : "v"(c));
+#define OP_MAX_F32(i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(f[i]) : "v"(c));
+#define OP_MAX3_F32(i) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(c), "v"(b));
+#define OP_CND(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(u[(i + 1) & 7]) : "vcc");
+#define OP_ADD_U32(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+#define OP_ADD_F64(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[i]) : "v"(cd));
+#define OP_MUL_F64(i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[i]) : "v"(bd));
+#define OP_FMA_F64(i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[i]) : "v"(bd), "v"(cd));
+#define OP_MAX_F64(i) asm volatile("v_max_f64 %0, %0, %1" : "+v"(d[i]) : "v"(cd));
+#define OP_RCP_F64(i) asm volatile("v_rcp_f64 %0, %0" : "+v"(d[i]));
+#define OP_SQRT_F32(i) asm volatile("v_sqrt_f32 %0, %0" : "+v"(f[i]));
+        for (int r = 0; r < 4; r++) {
+            if (KIND == FMA_F32) { CHAIN8(OP_FMA_F32) }
+            else if (KIND == PK_FMA_F32) { CHAIN8(OP_PK) }
+            else if (KIND == ADD_F32) { CHAIN8(OP_ADD_F32) }
+            else if (KIND == MAX_F32) { CHAIN8(OP_MAX_F32) }
+            else if (KIND == MAX3_F32) { CHAIN8(OP_MAX3_F32) }
+            else if (KIND == CNDMASK) { CHAIN8(OP_CND) }
+            else if (KIND == ADD_U32) { CHAIN8(OP_ADD_U32) }
+            else if (KIND == ADD_F64) { CHAIN8(OP_ADD_F64) }
+            else if (KIND == MUL_F64) { CHAIN8(OP_MUL_F64) }
+            else if (KIND == FMA_F64) { CHAIN8(OP_FMA_F64) }
+            else if (KIND == MAX_F64) { CHAIN8(OP_MAX_F64) }
+            else if (KIND == RCP_F64) { CHAIN8(OP_RCP_F64) }
+            else { CHAIN8(OP_SQRT_F32) }
+        }
     }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0;
+    for (int i = 0; i < 8; i++) s += f[i] + (float)d[i] + (float)u[i] + p[i].x + p[i].y;
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cycles[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
 }
-int main() {
-    float* d; hipMalloc(&d, 256 * 8 * 1024 * sizeof(float));
-    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
-    const int iters = 1 << 15;
-    for (int waves_per_simd : {1, 2, 4, 8}) {
-        int block = 256, blocks_per_cu = waves_per_simd;   // 256 threads = 4 waves = 1 wave per SIMD
-        int grid = p.multiProcessorCount * blocks_per_cu;
-        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        fma_loop<<<grid, block>>>(d, 64); hipDeviceSynchronize();
-        hipEventRecord(e0); fma_loop<<<grid, block>>>(d, iters); hipEventRecord(e1); hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        double wave_instr = (double)grid * (block / 64) * iters * 8.0;
-        double per_simd_per_s = wave_instr / (p.multiProcessorCount * 4) / (ms * 1e-3);
-        printf("waves/SIMD %d: %.3f ms, %.2f G wave-FMA/s per SIMD (clock ~2.4 GHz => %.2f cycles per wave-instr), %.1f TFLOP/s\n",
-               waves_per_simd, ms, per_simd_per_s / 1e9, 2.4e9 / per_simd_per_s, wave_instr * 128 / (ms * 1e-3) / 1e12);
+
+template <int KIND> void run(int n_cus, unsigned long long* d_cyc, float* d_sink, FILE* js, bool first) {
+    const int iters = 4096;
+    printf("%-14s", kind_name[KIND]);
+    if (js) fprintf(js, "%s\n  \"%s\": {", first ? "" : ",", kind_name[KIND]);
+    int col = 0;
+    for (int wps : {1, 2, 4, 8}) {
+        const int block = 256, grid = n_cus * wps;   // 256 threads = 4 waves = one wave per SIMD per resident block
+        loop_kernel<KIND><<<grid, block>>>(d_cyc, d_sink, 16);
+        hipDeviceSynchronize();
+        loop_kernel<KIND><<<grid, block>>>(d_cyc, d_sink, iters);
+        hipDeviceSynchronize();
+        const int n_waves = grid * 4;
+        std::vector<unsigned long long> h(n_waves);
+        hipMemcpy(h.data(), d_cyc, n_waves * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double sum = 0;
+        for (auto v : h) sum += (double)v;
+        const double per_wave = sum / n_waves;                       // cycles one wave needed for iters * 32 instructions
+        const double cyc_per_instr_simd = per_wave / (iters * 32.0) / wps;   // wps waves share the SIMD
+        printf("  %d w/SIMD: %5.2f", wps, cyc_per_instr_simd);
+        if (js) fprintf(js, "%s\"%d\": %.3f", col++ ? ", " : "", wps, cyc_per_instr_simd);
     }
+    printf("   cycles per wave64 instruction per SIMD\n");
+    if (js) fprintf(js, "}");
+}
+
+int main(int argc, char** argv) {
+    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+    unsigned long long* d_cyc; float* d_sink;
+    hipMalloc(&d_cyc, (size_t)p.multiProcessorCount * 8 * 4 * sizeof(unsigned long long));
+    hipMalloc(&d_sink, (size_t)p.multiProcessorCount * 8 * 256 * sizeof(float));
+    FILE* js = argc > 1 ? fopen(argv[1], "w") : nullptr;
+    if (js) fprintf(js, "{\"device\": \"%s\", \"cus\": %d, \"unit\": \"shader cycles (s_memtime) per wave64 instruction per SIMD, by resident waves per SIMD\"", p.name, p.multiProcessorCount);
+    run<FMA_F32>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<PK_FMA_F32>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<ADD_F32>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<MAX_F32>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<MAX3_F32>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<CNDMASK>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<ADD_U32>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<ADD_F64>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<MUL_F64>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<FMA_F64>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<MAX_F64>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<RCP_F64>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<SQRT_F32>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    if (js) { fprintf(js, "\n}\n"); fclose(js); }
     return 0;
 }

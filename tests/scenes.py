@@ -108,3 +108,43 @@ def moving_scene(width=96, samples=6, frame=0, null_motion=False, depth=8):
     for alias in ("tri_a", "tri_b"):
         sc.translate_point((1.5 * k, 0.8 * k, -1.0 * k), 1.0, LERP, LOCAL, alias)
     return sc
+
+
+def scaled_scene(width=96, samples=6, frame=0, depth=8):
+    """Triangles under every non-sphere scale builder (scene_animator.rs:38-229): ScaleX / ScaleY / ScaleZ keys, LERP and
+    NERP, scale_point and scale_all_uniform (whose Z key wins, timeline/mod.rs:249-255), mixed with translations; 1 fps
+    with a 360 degree shutter, so frame f draws ray times in [f, f + 1] and the keys change inside the exposure.
+    Default sky, solid and checker textures only: nothing goes through acos/atan2/asin, so renders are bit-exact."""
+    sc = Scene.new_image(16.0 / 9.0, width, 1, 360.0, 1)
+    cam = sc.scene_cam
+    cam.set_samples(samples)
+    cam.set_max_depth(depth)
+    cam.look_from((1.0, 3.0, 9.0))
+    cam.look_at((0.5, 1.0, 0.0))
+    cam.set_vfov(38.0)
+    cam.frame = frame
+    ground = Lambertian.new_from_texture(CheckerTexture.new_from_color(0.8, (0.2, 0.3, 0.1), (0.9, 0.9, 0.9)), 1.0)
+    sc.add_element(Sphere.new((0.0, -100.0, 0.0), 100.0, ground), "ground")
+    sc.add_element(Sphere.new((-3.0, 0.6, 1.0), 0.6, Dielectric.new(1.5)), "glass")
+    sc.add_element(Sphere.new((3.4, 0.5, 1.5), 0.5, Metal.new((0.8, 0.8, 0.9), 0.0)), "mirror")
+    m_quad = Metal.new((0.7, 0.7, 0.9), 0.1)
+    sc.add_element(Triangle.new((0.5, 0.0, -2.0), (2.5, 0.0, -2.0), (2.5, 2.0, -2.2), m_quad), "quad_a")
+    sc.add_element(Triangle.new((0.5, 0.0, -2.0), (2.5, 2.0, -2.2), (0.5, 2.0, -2.2), m_quad), "quad_b")
+    m_tet = Lambertian.new_from_texture(CheckerTexture.new_from_color(0.4, (0.9, 0.9, 0.2), (0.2, 0.2, 0.2)), 1.0)
+    p = [(1.0, 0.0, 1.5), (2.0, 0.0, 1.2), (1.5, 0.0, 2.3), (1.5, 1.0, 1.7)]
+    for k, (a, b, c) in enumerate([(0, 1, 3), (1, 2, 3), (2, 0, 3), (0, 2, 1)]):
+        sc.add_element(Triangle.new(p[a], p[b], p[c], m_tet), f"tet{k}")
+    m_fin = Lambertian.new_from_color((0.8, 0.3, 0.2), 1.0)
+    sc.add_element(Triangle.new((-1.5, 0.0, 0.5), (-0.5, 0.0, 0.8), (-1.0, 1.5, 0.6), m_fin), "fin")
+    for alias in ("quad_a", "quad_b"):
+        sc.scale_x(1.5, 1.0, LERP, alias)                 # X wins until the Y key starts
+        sc.scale_y(0.3, 0.5, NERP, alias)                 # from t = 0.5: y' = 0.3 * x + y (row 1, column 0)
+        sc.scale_y(-0.2, 2.5, LERP, alias)
+    for k in range(4):
+        sc.scale_all_uniform(1.3, 1.0, LERP, f"tet{k}")   # X, Y, Z keys over [0, 1]: Z is last and wins
+        sc.translate_point((0.4, 0.0, -0.5), 1.5, LERP, LOCAL, f"tet{k}")
+        sc.scale_z(0.8, 2.0, NERP, f"tet{k}")
+    sc.scale_point((0.5, 2.0, 1.5), 0.25, NERP, "fin")
+    sc.translate_point((-0.5, 0.3, 0.0), 0.75, NERP, LOCAL, "fin")
+    sc.scale_x(2.0, 1.75, LERP, "fin")
+    return sc

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(hiplib):
 
 def test_struct_layouts_match_header():
     structs = ["CrPrimitive", "CrMaterial", "CrTexture", "CrImage", "CrKeyframe", "CrSceneDesc", "CrCameraDesc",
-               "CrRenderParams", "CrStats"]
+               "CrRenderParams", "CrStats", "CrGroupStats"]
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "crucible_hip.h"\nint main(){\n'
     for s in structs:
         src += f'printf("{s} %zu\\n", sizeof({s}));\n'
@@ -61,6 +61,36 @@ def test_create_without_gpu_fails_loudly(hiplib):
     rc = hiplib.cr_create(0, C.byref(h))
     assert rc == A.CR_ERR_NO_DEVICE and not h.value
     assert b"no HIP device" in hiplib.cr_last_error(None)
+
+
+def test_group_entry_points_without_gpu(hiplib):
+    """The multi-GPU entry points: the shard arithmetic is pure (no device needed); creating a group without a HIP
+    device fails like cr_create; RCCL is not a link-time dependency (it is dlopen'ed when a group needs it)."""
+    import torch
+    from crucible_amd.distributed import shard_range
+    from crucible_amd.group import shard
+    for spp, world in ((512, 8), (512, 1), (10, 3), (4, 8), (0, 2), (1024, 6), (7, 7)):
+        ranges = [shard(spp, r, world) for r in range(world)]
+        assert ranges == [shard_range(r, world, spp) for r in range(world)]
+        assert ranges[0][0] == 0 and sum(n for _, n in ranges) == spp
+        assert all(ranges[r][0] + ranges[r][1] == ranges[r + 1][0] for r in range(world - 1))
+        assert max(n for _, n in ranges) - min(n for _, n in ranges) <= 1
+    b, n = C.c_int32(), C.c_int32()
+    for bad in ((8, 3, 3), (8, -1, 3), (8, 0, 0), (-1, 0, 1)):
+        assert hiplib.cr_group_shard(*bad, C.byref(b), C.byref(n)) == A.CR_ERR_INVALID_ARG
+    assert hiplib.cr_group_size(None) == 0 and hiplib.cr_group_rank(None) == -1 and not hiplib.cr_group_handle(None, 0)
+    hiplib.cr_group_destroy(None)
+    g = C.c_void_p()
+    assert hiplib.cr_group_create(None, 0, C.byref(g)) == A.CR_ERR_INVALID_ARG
+    two = (C.c_int32 * 2)(0, 0)
+    assert hiplib.cr_group_create(two, 2, C.byref(g)) == A.CR_ERR_INVALID_ARG and b"twice" in hiplib.cr_group_last_error(None)
+    assert hiplib.cr_group_create_rank(0, 3, 2, None, C.byref(g)) == A.CR_ERR_INVALID_ARG
+    if not torch.cuda.is_available():
+        one = (C.c_int32 * 1)(0)
+        assert hiplib.cr_group_create(one, 1, C.byref(g)) == A.CR_ERR_NO_DEVICE and not g.value
+        assert hiplib.cr_group_create_rank(0, 0, 1, None, C.byref(g)) == A.CR_ERR_NO_DEVICE
+    out = subprocess.check_output(["ldd", os.path.join(ROOT, "crucible_amd", "libcrucible_hip.so")]).decode()
+    assert "rccl" not in out and "nccl" not in out
 
 
 def test_null_arguments_are_rejected(hiplib):

@@ -1,0 +1,74 @@
+"""SURVEY 8(e) behind the C ABI: cr_group_* -- samples-per-pixel sharding + one RCCL reduce inside the library.
+The GPU box has one device, so what can run here is: a one-member group (must be bit-identical to
+cr_render_device), and the same group with the collective forced on (ncclCommInitAll / ncclCommInitRank with one
+rank, ncclReduce in place, the divide kernel) -- which exercises the dlopen'ed RCCL table, the call sequence and the
+sum -> mean step on real hardware.  More members are covered by the shard arithmetic (tests/test_abi.py), the gloo
+test of the reduce (tests/test_distributed_cpu.py) and the shard-sum tests of test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from crucible_amd import _abi as A
+from crucible_amd.demo_builder import book1_end_scene
+from crucible_amd.group import RenderGroup
+
+pytestmark = pytest.mark.gpu
+
+REALS = [(A.CR_REAL_F64, "f64"), (A.CR_REAL_F32, "f32")]
+COUNTERS = ("segments", "node_tests", "prim_tests", "texel_fetches")
+SEED = 0xC0FFEE
+
+
+def group_image(g, sc, rt):
+    import torch
+    cam = sc.scene_cam
+    t = torch.full((cam.image_height, cam.image_width, 3), -1.0, dtype=torch.float64 if rt == A.CR_REAL_F64 else torch.float32,
+                   device="cuda:0")
+    g.upload_scene(sc.flatten())
+    st = g.render_device(cam, t.data_ptr(), seed=SEED, real_type=rt)
+    return t.cpu().numpy(), st
+
+
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+@pytest.mark.parametrize("mode", ["local", "local+rccl", "rank", "rank+rccl"])
+def test_one_member_group_equals_render_device(renderer, oracles, monkeypatch, rt, tag, mode):
+    sc = book1_end_scene(1, scene_seed=1, image_width=96, samples=5)
+    single, sst = (renderer.upload_scene(sc.flatten()), renderer.render(sc.scene_cam, seed=SEED, real_type=rt))[1]
+    ref, rst = oracles[rt].render_image(sc, seed=SEED)
+    if mode.endswith("rccl"):
+        monkeypatch.setenv("CRUCIBLE_GROUP_FORCE_RCCL", "1")
+    g = RenderGroup.local([0]) if mode.startswith("local") else RenderGroup.rank(0, 0, 1, RenderGroup.unique_id() if mode.endswith("rccl") else None)
+    try:
+        assert (g.size, g.local_size, g.first_rank) == (1, 1, 0)
+        img, st = group_image(g, sc, rt)
+        assert st["used_rccl"] == (1 if mode.endswith("rccl") else 0) and st["members"] == 1
+        assert np.array_equal(img, single) and np.array_equal(img, ref)      # sum of one shard / samples == the mean
+        for k in COUNTERS:
+            assert st[k] == sst[k] == rst[k], k
+        assert st["samples"] == 96 * 54 * 5 and st["kernel_ms"] > 0
+        again, _ = group_image(g, sc, rt)
+        assert np.array_equal(again, img)
+    finally:
+        g.close()
+
+
+def test_group_handles_drive_frame_sharding(renderer):
+    """Movies shard whole frames (frame f -> member f % G, scene/mod.rs:307-316): the member handle is an ordinary
+    CrHandle."""
+    import ctypes as C
+    import torch
+    sc = book1_end_scene(1, scene_seed=1, image_width=64, samples=2)
+    g = RenderGroup.local([0])
+    try:
+        g.upload_scene(sc.flatten())
+        h = g.lib.cr_group_handle(g.g, 0)
+        assert h and not g.lib.cr_group_handle(g.g, 1)
+        cam = sc.scene_cam
+        t = torch.zeros((cam.image_height, cam.image_width, 3), dtype=torch.float32, device="cuda:0")
+        cd, p = cam.desc(), cam.params(SEED, A.CR_REAL_F32)
+        assert g.lib.cr_render_device(h, C.byref(cd), C.byref(p), C.c_void_p(t.data_ptr()), None) == A.CR_OK
+        assert g.lib.cr_synchronize(h) == A.CR_OK
+        renderer.upload_scene(sc.flatten())
+        ref, _ = renderer.render(cam, seed=SEED, real_type=A.CR_REAL_F32)
+        assert np.array_equal(t.cpu().numpy(), ref)
+    finally:
+        g.close()

@@ -302,19 +302,20 @@ def test_determinism_and_seed_dependence(renderer):
     assert np.array_equal(a, b) and not np.array_equal(a, c)
 
 
-def test_full_size_properties(renderer, oracles):
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+def test_full_size_properties(renderer, oracles, rt, tag):
     """BASELINE config 2's frame (book1 1920x1080) at 2 spp: every pixel in [0,1], rows spot-checked
     bit-for-bit against the oracle, two runs identical, shards add up, PPM bytes follow."""
     sc = book1_end_scene(1, scene_seed=1, image_width=1920, samples=2)
     cam = sc.scene_cam
     assert (cam.image_width, cam.image_height) == (1920, 1080)
     renderer.upload_scene(sc.flatten())
-    img, st = renderer.render(cam, seed=SEED, real_type=A.CR_REAL_F32)
+    img, st = renderer.render(cam, seed=SEED, real_type=rt)
     assert st["samples"] == 1920 * 1080 * 2 and st["nan_pixels"] == 0
     assert img.min() >= 0.0 and img.max() <= 1.0
-    again, st2 = renderer.render(cam, seed=SEED, real_type=A.CR_REAL_F32)
+    again, st2 = renderer.render(cam, seed=SEED, real_type=rt)
     assert np.array_equal(img, again) and all(st[k] == st2[k] for k in COUNTERS)
-    o = oracles[A.CR_REAL_F32]
+    o = oracles[rt]
     h = o.scene_create(sc.flatten())
     try:
         for row in (0, 1, 311, 540, 777, 1079):
@@ -322,9 +323,9 @@ def test_full_size_properties(renderer, oracles):
             assert np.array_equal(img[row], ref), row
     finally:
         o.scene_destroy(h)
-    s0, _ = renderer.render(cam, seed=SEED, real_type=A.CR_REAL_F32, sample_begin=0, sample_count=1, output_sum=True)
-    s1, _ = renderer.render(cam, seed=SEED, real_type=A.CR_REAL_F32, sample_begin=1, sample_count=1, output_sum=True)
-    assert np.array_equal((s0 + s1) / np.float32(2), img)     # two-term f32 sum has one order
+    s0, _ = renderer.render(cam, seed=SEED, real_type=rt, sample_begin=0, sample_count=1, output_sum=True)
+    s1, _ = renderer.render(cam, seed=SEED, real_type=rt, sample_begin=1, sample_count=1, output_sum=True)
+    assert np.array_equal((s0 + s1) / img.dtype.type(2), img)     # a two-term sum has one order
     q = quantize_rgb8(img)
     assert q.shape == img.shape and np.array_equal(q, (255.0 * np.sqrt(img.astype(np.float64))).astype(np.uint8))
 
@@ -451,19 +452,21 @@ def test_sample_batches_keep_the_sequential_sum(oracles, monkeypatch, rt, tag):
         r.close()
 
 
-def test_headline_config_at_full_sample_count(renderer, oracles):
-    """BASELINE config 2 exactly as benchmarked (book1 1920x1080 @ 512 spp, depth 50, f32): two renders identical,
-    two rows bit-for-bit against the oracle at all 512 samples (the sequential per-pixel sum through 512 terms),
-    and eight 64-sample shards add up to the frame within f32 re-association error (the multi-GPU split)."""
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+def test_headline_config_at_full_sample_count(renderer, oracles, rt, tag):
+    """BASELINE config 2 exactly as benchmarked (book1 1920x1080 @ 512 spp, depth 50; f64 is the headline arithmetic,
+    the reference's): two renders identical, two rows bit-for-bit against the oracle at all 512 samples (the
+    sequential per-pixel sum through 512 terms), and eight 64-sample shards add up to the frame within re-association
+    error (the multi-GPU split)."""
     sc = book1_end_scene(1, scene_seed=1, image_width=1920, samples=512)
     cam = sc.scene_cam
     renderer.upload_scene(sc.flatten())
-    img, st = renderer.render(cam, seed=SEED, real_type=A.CR_REAL_F32)
-    again, st2 = renderer.render(cam, seed=SEED, real_type=A.CR_REAL_F32)
+    img, st = renderer.render(cam, seed=SEED, real_type=rt)
+    again, st2 = renderer.render(cam, seed=SEED, real_type=rt)
     assert st["samples"] == 1920 * 1080 * 512 and st["nan_pixels"] == 0
     assert np.array_equal(img, again) and all(st[k] == st2[k] for k in COUNTERS)
     assert img.min() >= 0.0 and img.max() <= 1.0
-    o = oracles[A.CR_REAL_F32]
+    o = oracles[rt]
     h = o.scene_create(sc.flatten())
     try:
         for row in (97, 803):
@@ -473,6 +476,88 @@ def test_headline_config_at_full_sample_count(renderer, oracles):
         o.scene_destroy(h)
     total = np.zeros(img.shape, dtype=np.float64)
     for k in range(8):
-        part, _ = renderer.render(cam, seed=SEED, real_type=A.CR_REAL_F32, sample_begin=64 * k, sample_count=64, output_sum=True)
+        part, _ = renderer.render(cam, seed=SEED, real_type=rt, sample_begin=64 * k, sample_count=64, output_sum=True)
         total += part
-    assert np.abs(total / 512.0 - img).max() < 2e-5
+    assert np.abs(total / 512.0 - img).max() < (2e-5 if rt == A.CR_REAL_F32 else 1e-13)
+
+
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+@pytest.mark.parametrize("pipeline", ["mega", "wavefront", "queue", "pixel-granular"])
+def test_empty_sample_shard(oracles, monkeypatch, rt, tag, pipeline):
+    """More ranks than samples leaves some ranks with sample_count = 0 (distributed.shard_range): cast_ray's loop body
+    never runs (ray_casting.rs:82), the sum is zero and so is 0 / samples.  No kernel may spin on an empty range."""
+    from crucible_amd.distributed import shard_range
+    from crucible_amd.renderer import Renderer
+    if pipeline == "pixel-granular":
+        monkeypatch.setenv("CRUCIBLE_SAMPLE_GRANULAR", "0")
+    else:
+        monkeypatch.setenv("CRUCIBLE_PIPELINE", pipeline)
+    r = Renderer(0)
+    try:
+        sc = book1_end_scene(1, scene_seed=1, image_width=48, samples=4)
+        r.upload_scene(sc.flatten())
+        cam = sc.scene_cam
+        b, n = shard_range(5, 8, cam.samples)
+        assert n == 0
+        o = oracles[rt]
+        h = o.scene_create(sc.flatten())
+        try:
+            for output_sum in (True, False):
+                img, st = r.render(cam, seed=SEED, real_type=rt, sample_begin=b, sample_count=n, output_sum=output_sum)
+                ref, _ = o.render(h, cam, seed=SEED, sample_begin=b, sample_count=n, output_sum=output_sum)
+                assert not img.any() and np.array_equal(img.reshape(-1, 3), ref) and st["samples"] == 0
+        finally:
+            o.scene_destroy(h)
+        full, _ = r.render(cam, seed=SEED, real_type=rt)     # the handle is fine afterwards
+        ref, _ = o.render_image(sc, seed=SEED)
+        assert np.array_equal(full, ref)
+    finally:
+        r.close()
+
+
+def test_back_to_back_async_renders_keep_their_own_camera_keys(renderer):
+    """cr_render_device is asynchronous without stats; a movie queues frames back to back, each with its own camera
+    keyframes.  The keys of a launch travel in a per-launch slot, so six queued frames with six different key sets
+    (more than the ring holds) equal the same frames rendered one at a time."""
+    import torch
+    sc = book1_end_scene(1, scene_seed=1, image_width=96, samples=3)
+    renderer.upload_scene(sc.flatten())
+    cam = sc.scene_cam
+    outs, refs = [], []
+    targets = [(13.0 - 2.0 * k, 2.0 + 0.5 * k, 3.0 + k) for k in range(6)]
+    for k, tgt in enumerate(targets):
+        cam.look_from((13.0, 2.0, 3.0))
+        cam.look_from_tl.translate_point(tgt, 0.01 + 0.002 * k, scenes.NERP if k % 2 else scenes.LERP, scenes.WORLD)
+        img, _ = renderer.render(cam, seed=SEED, real_type=A.CR_REAL_F32)
+        refs.append(img)
+    for k, tgt in enumerate(targets):
+        cam.look_from((13.0, 2.0, 3.0))
+        cam.look_from_tl.translate_point(tgt, 0.01 + 0.002 * k, scenes.NERP if k % 2 else scenes.LERP, scenes.WORLD)
+        t = torch.zeros((cam.image_height, cam.image_width, 3), dtype=torch.float32, device="cuda:0")
+        renderer.render_device(cam, t.data_ptr(), seed=SEED, real_type=A.CR_REAL_F32)   # queued, not waited for
+        outs.append(t)
+    renderer.synchronize()
+    for k in range(6):
+        assert np.array_equal(outs[k].cpu().numpy(), refs[k]), k
+    assert not np.array_equal(refs[0], refs[5])
+
+
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+def test_checker_nesting_limit(renderer, oracles, rt, tag):
+    """Checker textures nest arbitrarily in the reference (checker_texture.rs:12-13); the device resolves a chain of
+    at most CR_MAX_CHECKER_DEPTH levels: 32 levels render bit-exactly, 33 are refused at upload (never shaded wrong)."""
+    from crucible_amd.scene import CheckerTexture, Lambertian, SolidColor
+    def chain(depth):
+        t = SolidColor((0.9, 0.2, 0.1))
+        for k in range(depth):
+            t = CheckerTexture.new_from_textures(0.3 + 0.05 * k, t, SolidColor((0.1 + 0.02 * k, 0.5, 0.9 - 0.02 * k)))
+        return t
+    sc = scenes.few_spheres(3, width=64, samples=3)
+    sc.elements[0].mat = Lambertian.new_from_texture(chain(A.CR_MAX_CHECKER_DEPTH), 1.0)
+    img, st = gpu_render(renderer, sc, rt)
+    ref, rst = oracles[rt].render_image(sc, seed=SEED)
+    assert_exact(img, st, ref, rst)
+    sc.elements[0].mat = Lambertian.new_from_texture(chain(A.CR_MAX_CHECKER_DEPTH + 1), 1.0)
+    with pytest.raises(CrucibleError) as e:
+        renderer.upload_scene(sc.flatten())
+    assert e.value.code == A.CR_ERR_UNSUPPORTED

@@ -135,3 +135,47 @@ def test_check_nerp_translate(o):   # src/timeline/mod.rs:333
     assert r0[0] == 2.0 and r0[1] == 3.0
     r5 = _eval(o, tl, 5.0)
     assert r5[0] == 3.0 and r5[1] == 13.0
+
+
+# ---- ScaleX / ScaleY / ScaleZ of non-sphere timelines.  The reference holds no test for them; these are hand
+# evaluations of S * T * (0,0,0,1) with the matrices transform_builder.rs:101-346 builds (ScaleY's factor sits in
+# row 1, column 0, :228-246) and the "last active scale wins" rule of timeline/mod.rs:249-255.
+def test_scale_axis_matrices(o):
+    p = (1.0, 2.0, 3.0)
+    tl = TransformTimeline(p); tl.scale_x(3.0, 1.0, NERP)
+    assert list(_eval(o, tl, 0.5)[:3]) == [1.0, 2.0, 3.0] and list(_eval(o, tl, 1.0)[:3]) == [3.0, 2.0, 3.0]
+    tl = TransformTimeline(p); tl.scale_z(3.0, 1.0, NERP)
+    assert list(_eval(o, tl, 2.0)[:3]) == [1.0, 2.0, 9.0]
+    tl = TransformTimeline(p); tl.scale_y(3.0, 1.0, NERP)       # y' = 3 * x + y: the (1,0) slot, not the diagonal
+    assert list(_eval(o, tl, 2.0)[:3]) == [1.0, 5.0, 3.0]
+    assert _eval(o, tl, 2.0)[3] == 1.0 and _eval(o, tl, 0.0)[3] == 1.0
+
+
+def test_scale_axis_lerp_and_last_active_wins(o):
+    tl = TransformTimeline((1.0, 2.0, 3.0))
+    tl.scale_x(3.0, 2.0, LERP)                                  # 1 + (3 - 1) * t/2 over [0, 2]
+    assert list(_eval(o, tl, 1.0)[:3]) == [2.0, 2.0, 3.0] and list(_eval(o, tl, 7.0)[:3]) == [3.0, 2.0, 3.0]
+    tl.scale_z(0.5, 1.5, NERP)                                  # starts at 1.5: from then on it is the last active scale
+    assert list(_eval(o, tl, 1.0)[:3]) == [2.0, 2.0, 3.0]
+    assert list(_eval(o, tl, 1.5)[:3]) == [1.0, 2.0, 1.5] and list(_eval(o, tl, 9.0)[:3]) == [1.0, 2.0, 1.5]
+    tl = TransformTimeline((1.0, 2.0, 3.0))
+    tl.scale_point((2.0, 3.0, 4.0), 1.0, NERP)                  # X, Y, Z pushed with one interval: Z is last
+    assert list(_eval(o, tl, 1.0)[:3]) == [1.0, 2.0, 12.0]
+    tl.translate_x(4.0, 0.5, NERP, LOCAL)                       # translate first, then scale: S * T
+    tl.scale_y(0.5, 3.0, LERP)                                  # previous ScaleY ended at 3.0, t = 1: 3 + (0.5 - 3) * s
+    assert list(_eval(o, tl, 2.0)[:3]) == [5.0, (3.0 + (0.5 - 3.0) * 0.5) * 5.0 + 2.0, 3.0]
+
+
+def test_scale_keys_flatten_in_list_order():
+    """The scale list after scaled_teapot's calls, worked by hand from most_recent_matching_transform
+    (helper_functions.rs:41-140) and the stable sort by start time (transform_builder.rs `sort_by compare_start`)."""
+    from crucible_amd.demo_builder import scaled_teapot
+    sc = scaled_teapot(1)
+    f = sc.flatten()
+    n = f.prims[0].key_count
+    got = [(k.channel, k.interp, k.t0, k.t1, k.a, k.b) for k in f.keys[:n]]
+    assert got == [(0, 1, 0.0, 0.02, 0.0, 0.0), (1, 1, 0.0, 0.02, 0.4, 0.0), (2, 1, 0.0, 0.02, 0.3, 0.0),
+                   (4, 1, 0.0, 0.012, 1.0, 1.4), (6, 1, 0.0, 0.05, 1.0, 1.2), (4, 1, 0.012, 0.05, 1.4, 1.2),
+                   (5, 0, 0.016, 0.016, 0.25, 0.0), (5, 1, 0.016, 0.05, 0.25, 1.2), (6, 1, 0.05, 0.09, 1.2, 0.7)]
+    with pytest.raises(ValueError):
+        sc.scale_x(2.0, 1.0, LERP, "ground")                    # "ScaleX cannot apply to Spheres" (scene_animator.rs:39-41)

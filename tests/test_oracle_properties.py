@@ -302,3 +302,18 @@ def test_rng_streams_look_uniform_and_independent(o64):
     # a different seed gives a different stream
     o64.lib.oracle_rng_uniforms(1235, 0, 0, n_draw, buf.ctypes.data)
     assert not np.array_equal(buf, u[0, 0])
+
+
+@pytest.mark.parametrize("frame", [0, 1, 2])
+def test_refit_boxes_with_scale_keys_against_the_linear_list(o64, frame):
+    """Triangles under ScaleX/ScaleY/ScaleZ keys move along products of piecewise-linear functions; the refit rule
+    samples their translate and scale parts independently (refit.hpp) and must still enclose them."""
+    import scenes
+    sc = scenes.scaled_scene(96, 3, frame=frame)
+    sc.scene_cam.refit_boxes = False
+    truth, _ = o64.render_image(sc, seed=9, linear_list=True)
+    stale, _ = o64.render_image(sc, seed=9)
+    sc.scene_cam.refit_boxes = True
+    fitted, _ = o64.render_image(sc, seed=9)
+    assert (fitted == truth).all(axis=2).mean() >= 0.995
+    assert (stale == truth).all(axis=2).mean() < 0.98
