@@ -108,7 +108,7 @@ struct CrHandle {
     // Sample-granular scheduling of the megakernel (pathtrace.hpp, KernelArgs::sg_on): on by default; the per-sample
     // colour buffer may take up to sample_buf_limit bytes (more samples than fit are rendered in batches).
     int sample_granular = 1;             // CRUCIBLE_SAMPLE_GRANULAR=0: a lane owns a pixel (no buffer)
-    size_t sample_buf_limit = (size_t)16 << 30;   // CRUCIBLE_SAMPLE_BUF_MB
+    size_t sample_buf_limit = (size_t)40 << 30;   // CRUCIBLE_SAMPLE_BUF_MB (MI355X: 288 GB of HBM)
     int sg_lw = -1, sg_lh = -1;          // CRUCIBLE_SG_TILE=WxH (powers of two, W*H <= 64); default 4x4 pixels x 4 samples
     // f32 trees with more than latency_entries wrappers run on pathtrace_kernel_latency (6 waves/SIMD) with a
     // latency_top_bytes LDS window, three 512-thread groups per CU.  CRUCIBLE_LATENCY_ENTRIES (0 = never).
@@ -705,7 +705,10 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
         const uint64_t max_groups = 0xF0000000ull / (tiles * 64);
         if (max_groups < 1) batch = 0;
         else batch = (int32_t)std::min<uint64_t>((uint64_t)batch, max_groups * ns);
-        if (batch > 0 && h->sample_buf.ensure((size_t)batch * per_sample) != hipSuccess) { (void)hipGetLastError(); batch = 0; }
+        // the buffer holds one colour per work item of a batch: whole tiles and whole sample groups (edge padding included)
+        auto batch_bytes = [&](int32_t b) { return (size_t)tiles * ((size_t)(b + (int32_t)ns - 1) / ns) * 64u * 3u * sizeof(real); };
+        while (batch > (int32_t)ns && batch_bytes(batch) > std::max(h->sample_buf_limit, batch_bytes((int32_t)ns))) batch -= (int32_t)ns;
+        if (batch > 0 && h->sample_buf.ensure(batch_bytes(batch)) != hipSuccess) { (void)hipGetLastError(); batch = 0; }
         if (batch > 0 && batch < s_end - s_begin && h->sg_acc.ensure(per_sample) != hipSuccess) { (void)hipGetLastError(); batch = 0; }
         if (batch == 0) { args.tiles_x = args_in.tiles_x; args.tiles_y = args_in.tiles_y; }   // fall back: a lane owns a pixel
     }
@@ -722,7 +725,7 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
     size_t stack_bytes = (size_t)3 * (size_t)(args.max_depth > 0 ? args.max_depth : 1) * args.n_threads * sizeof(real);
     HIP_TRY(h, h->att_stack.ensure(stack_bytes));
     args.att_stack = (real*)h->att_stack.p;
-    HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 16 * sizeof(uint64_t), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 64 * sizeof(uint64_t), h->stream));
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     if (!args.sg_on) {
         HIP_TRY(h, hipMemsetAsync(h->work_counter.p, 0, 4, h->stream));
@@ -738,7 +741,8 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
             HIP_TRY(h, hipMemsetAsync(h->work_counter.p, 0, 4, h->stream));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(block), LDS ? lds_bytes : 0, h->stream, args);
             HIP_TRY(h, hipGetLastError());
-            hipLaunchKernelGGL((sg_finalize_kernel<real>), dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, h->stream, args,
+            const size_t fin_threads = ((size_t)args.tiles_x * args.tiles_y) << (args.sg_lw + args.sg_lh);
+            hipLaunchKernelGGL((sg_finalize_kernel<real>), dim3((unsigned)((fin_threads + 255) / 256)), dim3(256), 0, h->stream, args,
                                (real*)h->sg_acc.p, b1 - b0, b0 == s_begin ? 1 : 0, b1 == s_end ? 1 : 0);
             HIP_TRY(h, hipGetLastError());
         }
@@ -761,12 +765,14 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
         stats->scene_in_lds = RES;
 #ifdef CR_DIAG
         {
-            uint64_t d[16];
+            uint64_t d[64];
             HIP_TRY(h, hipMemcpy(d, h->counters.p, sizeof d, hipMemcpyDeviceToHost));
-            const char* names[] = {"outer_iters(wave)", "inner_lane_steps", "inner_wave_steps", "leaf_lane_steps", "leaf_wave_steps", "clk_regen", "clk_trace",
-                                   "clk_shade", "clk_total", "shade_lane_sum", "trace_lane_sum", "regen_lane_sum"};
-            fprintf(stderr, "[diag] block=%d grid=%u", block, grid);
-            for (int i = 0; i < 12; i++) fprintf(stderr, " %s=%llu", names[i], (unsigned long long)d[4 + i]);
+            const char* names[] = {"box_wave", "box_lane", "prim_wave", "prim_lane", "round_wave", "round_lane", "leafph_wave", "leafph_lane",
+                                   "shade_wave", "shade_lane", "lamb_lane", "metal_lane", "diel_lane", "sky_lane", "ruv_wave", "ruv_lane",
+                                   "regen_wave", "regen_lane", "outer_wave", "unwind_wave", "unwind_lane", "hitsh_wave", "hitsh_lane"};
+            fprintf(stderr, "[diag] block=%d grid=%u clk_regen=%llu clk_trace=%llu clk_shade=%llu clk_total=%llu", block, grid,
+                    (unsigned long long)d[9], (unsigned long long)d[10], (unsigned long long)d[11], (unsigned long long)d[12]);
+            for (int i = 0; i < DG_N; i++) fprintf(stderr, " %s=%llu", names[i], (unsigned long long)d[16 + i]);
             fprintf(stderr, "\n");
         }
 #endif
@@ -796,7 +802,7 @@ int32_t launch_queue(CrHandle* h, const KernelArgs<real>& args_in, size_t scene_
     HIP_TRY(h, h->att_stack.ensure((size_t)3 * (size_t)std::max(1, args.max_depth) * args.n_threads * sizeof(real)));
     args.att_stack = (real*)h->att_stack.p;
     HIP_TRY(h, hipMemsetAsync(h->work_counter.p, 0, 4, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 16 * sizeof(uint64_t), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 64 * sizeof(uint64_t), h->stream));
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(QK_SLOTS), lds_bytes, h->stream, args);
     HIP_TRY(h, hipGetLastError());
@@ -851,7 +857,7 @@ int32_t wf_run(CrHandle* h, WfArgs<real>& W, size_t lds_bytes, int32_t s_begin, 
     const size_t npix = (size_t)W.k.cam.W * W.k.cam.H;
     const uint32_t logic_grid = (W.n_slots + 255) / 256;
     const uint32_t fin_grid = (uint32_t)((npix + 255) / 256);
-    HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 16 * sizeof(uint64_t), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 64 * sizeof(uint64_t), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->wf_acc.p, 0, npix * 3 * sizeof(real), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->wf_job.p, 0xFF, (size_t)W.n_slots * 4, h->stream));
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
@@ -1214,7 +1220,7 @@ int32_t cr_create(int32_t device_id, CrHandle** out) {
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = h->work_counter.ensure(16)) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = h->counters.ensure(16 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = h->counters.ensure(64 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
     if (const char* s = getenv("CRUCIBLE_LDS_LIMIT")) h->lds_limit = (size_t)atol(s);
     if (const char* s = getenv("CRUCIBLE_SAMPLE_GRANULAR")) h->sample_granular = atoi(s) != 0;
     if (const char* s = getenv("CRUCIBLE_SAMPLE_BUF_MB")) h->sample_buf_limit = (size_t)std::max(0L, atol(s)) << 20;

@@ -228,12 +228,13 @@ template <typename real> struct KernelArgs {
     // in a register.  sg_on = 1: a work item is one (pixel, sample); 64 consecutive items are a tile of
     // 2^sg_lw x 2^sg_lh pixels times 64 >> (sg_lw + sg_lh) consecutive samples, tiles_x/tiles_y count those tiles,
     // sg_groups such groups cover a tile's samples [sample_begin, sample_end), and each finished sample's colour
-    // goes to sample_buf[((sample - sample_begin) * W*H + pixel) * 3] for sg_finalize_kernel to add in order.
+    // goes to sample_buf[item * 3 .. +2], item = its work-item index: the 64 colours of a group are one contiguous run
+    // written by one wave (they merge in that XCD's L2 into whole lines), and sg_finalize_kernel adds them in order.
     uint32_t sg_on, sg_lw, sg_lh, sg_groups;
     uint32_t sg_total;        // work items of the launch (tiles * sg_groups * 64)
     real* sample_buf;
     uint64_t* counters;       // [0] segments [1] node tests [2] prim tests [3] texel fetches
-    real* att_stack;          // 3 planes of max_depth * n_threads
+    real* att_stack;          // max_depth * n_threads records of 3 reals, level-major
     uint32_t n_threads;
     real* out;
     uint32_t walk_exit_lanes;   // megakernel: leave the walk once this many lanes are done walking (speed only)
@@ -308,6 +309,24 @@ template <typename real> CR_HD CamFrame<real> camera_frame(const CamConst<real>&
 
 #if defined(__HIPCC__)
 // ================================================================== device only
+
+// Diagnostic build (-DCR_DIAG, scripts/diag only): per-lane event counts that the megakernel sums per wave and adds
+// to counters[16 + i]; "wave" counts are taken by the first active lane of the wave at that point, "lane" counts by
+// every active lane, so lane / (64 * wave) is the lane occupancy of that piece of code.  The product build compiles
+// none of it (Diag is empty, CR_DIAG_* expand to nothing).
+#ifdef CR_DIAG
+enum { DG_BOX_WAVE = 0, DG_BOX_LANE, DG_PRIM_WAVE, DG_PRIM_LANE, DG_ROUND_WAVE, DG_ROUND_LANE, DG_LEAFPH_WAVE, DG_LEAFPH_LANE,
+       DG_SHADE_WAVE, DG_SHADE_LANE, DG_LAMB_LANE, DG_METAL_LANE, DG_DIEL_LANE, DG_SKY_LANE, DG_RUV_WAVE, DG_RUV_LANE,
+       DG_REGEN_WAVE, DG_REGEN_LANE, DG_OUTER_WAVE, DG_UNWIND_WAVE, DG_UNWIND_LANE, DG_HITSH_WAVE, DG_HITSH_LANE, DG_N };
+struct Diag { uint32_t v[DG_N]; };
+#define CR_DIAG_LEADER() ((threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)__ballot(1)) - 1))
+#define CR_DIAG_HIT(dg, wave_i, lane_i) do { if (dg) { (dg)->v[lane_i]++; if (CR_DIAG_LEADER()) (dg)->v[wave_i]++; } } while (0)
+#define CR_DIAG_LANE(dg, lane_i) do { if (dg) (dg)->v[lane_i]++; } while (0)
+#else
+struct Diag {};
+#define CR_DIAG_HIT(dg, wave_i, lane_i) ((void)0)
+#define CR_DIAG_LANE(dg, lane_i) ((void)0)
+#endif
 
 template <typename real> struct Hit {
     real t;
@@ -477,13 +496,15 @@ CR_D void camera_ray(const KernelArgs<real>& A, uint32_t pix_i, uint32_t pix_j, 
 // What ray_color does after the closest-hit query (ray_casting.rs:122-151) for a path whose hit is
 // (best_t, best) -- best < 0 is a miss.  Returns true when the path is finished (col = the colour the
 // outermost ray_color call returns), false when it scattered (ro/rd replaced, depth_left decremented).
-// The path's non-unit attenuations live at att_stack[(level * stack_stride + stack_slot)] (3 planes).
+// The path's non-unit attenuations live at att_stack[(level * stack_stride + stack_slot) * 3 .. +2]: one record per
+// level, so a push is one contiguous store and an unwind step one contiguous load.
 template <typename real, bool ANIM>
 CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<real>* mats, const Tex<real>* texs, V3<real>& ro, V3<real>& rd,
                 real rtime, uint64_t& rng, int32_t& depth_left, int32_t& stack_n, real best_t, int32_t best, uint32_t stack_stride,
-                uint32_t stack_slot, uint32_t& c_tex, V3<real>& col) {
-    const size_t plane = (size_t)A.max_depth * stack_stride;
+                uint32_t stack_slot, uint32_t& c_tex, V3<real>& col, Diag* dg = nullptr) {
+    CR_DIAG_HIT(dg, DG_SHADE_WAVE, DG_SHADE_LANE);
     if (best >= 0) {
+        CR_DIAG_HIT(dg, DG_HITSH_WAVE, DG_HITSH_LANE);
         const Prim<real>& p = prims[best];
         V3<real> loc = add(ro, scale(best_t, rd));   // Ray::at
         V3<real> n;
@@ -532,7 +553,20 @@ CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<re
         // Lambertian and Metal both begin their draws with random_unit_vector() (lambertian.rs:41,
         // metal.rs:31): one shared pass of the rejection loop serves both groups of lanes
         V3<real> ruv = mk<real>(0, 0, 0);
+#ifdef CR_DIAG
+        if (m.kind != 2) {   // random_unit_vector with its rounds counted
+            for (;;) {
+                CR_DIAG_HIT(dg, DG_RUV_WAVE, DG_RUV_LANE);
+                real x = rng_range<real>(rng, real(-1), real(1)), y = rng_range<real>(rng, real(-1), real(1)), z = rng_range<real>(rng, real(-1), real(1));
+                V3<real> pp = mk<real>(x, y, z);
+                real lensq = len2(pp);
+                if (RealTraits<real>::tiny < lensq && lensq <= real(1)) { ruv = divs(pp, r_sqrt(lensq)); break; }
+            }
+        }
+        CR_DIAG_LANE(dg, m.kind == 0 ? DG_LAMB_LANE : (m.kind == 1 ? DG_METAL_LANE : DG_DIEL_LANE));
+#else
         if (m.kind != 2) ruv = random_unit_vector<real>(rng);
+#endif
         if (m.kind == 0) {                                  // lambertian.rs:40-61
             V3<real> dir = add(n, ruv);
             real tol = real(1e-8);
@@ -572,14 +606,15 @@ CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<re
         // factor and multiply on the way back (ray_casting.rs:128).  (1,1,1) multiplies exactly and
         // need not be stored.
         if (m.kind != 2) {
-            size_t at = (size_t)stack_n * stack_stride + stack_slot;
-            A.att_stack[at] = att.x; A.att_stack[plane + at] = att.y; A.att_stack[2 * plane + at] = att.z;
+            real* rec = A.att_stack + ((size_t)stack_n * stack_stride + stack_slot) * 3;
+            rec[0] = att.x; rec[1] = att.y; rec[2] = att.z;
             stack_n++;
         }
         ro = loc; rd = ndir; depth_left--;
         return false;
     }
     // sky (ray_casting.rs:133-151)
+    CR_DIAG_LANE(dg, DG_SKY_LANE);
     V3<real> ud = unit(rd);
     if (A.sky_kind == 1) {
         real theta = r_atan2(ud.x, ud.z);
@@ -595,18 +630,20 @@ CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<re
     // per round trip and applied innermost-first, so the product is formed in the reference's order.
     int32_t k = stack_n - 1;
     for (; k >= 3; k -= 4) {
+        CR_DIAG_HIT(dg, DG_UNWIND_WAVE, DG_UNWIND_LANE);
         V3<real> a[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            size_t at = (size_t)(k - j) * stack_stride + stack_slot;
-            a[j] = mk<real>(A.att_stack[at], A.att_stack[plane + at], A.att_stack[2 * plane + at]);
+            const real* rec = A.att_stack + ((size_t)(k - j) * stack_stride + stack_slot) * 3;
+            a[j] = mk<real>(rec[0], rec[1], rec[2]);
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) col = c_mul(a[j], col);
     }
     for (; k >= 0; k--) {
-        size_t at = (size_t)k * stack_stride + stack_slot;
-        V3<real> a_k = mk<real>(A.att_stack[at], A.att_stack[plane + at], A.att_stack[2 * plane + at]);
+        CR_DIAG_HIT(dg, DG_UNWIND_WAVE, DG_UNWIND_LANE);
+        const real* rec = A.att_stack + ((size_t)k * stack_stride + stack_slot) * 3;
+        V3<real> a_k = mk<real>(rec[0], rec[1], rec[2]);
         col = c_mul(a_k, col);
     }
     return true;
@@ -667,11 +704,12 @@ template <typename real> CR_D void walk_begin(WalkState<real>& w, V3<real> rd) {
 // ORD: the ordered layout (EntryO behind the same pointers) -- near child first, per-octant skip links.
 template <typename real, int RES, bool ANIM, bool ORD = false>
 CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, const Prim<real>* prims, V3<real> ro, V3<real> rd, real rtime,
-                     WalkState<real>& w, bool walking, uint32_t budget, unsigned long long& c_node, uint32_t& c_prim) {
+                     WalkState<real>& w, bool walking, uint32_t budget, unsigned long long& c_node, uint32_t& c_prim, Diag* dg = nullptr) {
     const real tmin = real(0.001);
     const int32_t n_entries = A.n_entries;
     int32_t leaf = -1;
     if (walking) {
+        CR_DIAG_HIT(dg, DG_ROUND_WAVE, DG_ROUND_LANE);
         if (!w.exact_box) {
             const Pair<real> ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
             const Pair<real> ix = {w.inv.x, w.inv.x}, iy = {w.inv.y, w.inv.y}, iz = {w.inv.z, w.inv.z};
@@ -682,6 +720,7 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
                 const Entry<real> e = ORD ? fetch_entry_ordered<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx, w.oct)
                                           : fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx);
                 nodes++;
+                CR_DIAG_HIT(dg, DG_BOX_WAVE, DG_BOX_LANE);
                 const bool miss = box_miss_fast(e.b, ox, oy, oz, ix, iy, iz, tmin, tmax);
                 const bool inner = e.leaf < 0;
                 w.idx = (inner && !miss) ? (ORD ? ordered_near(e.leaf, w.oct) : -e.leaf) : e.skip;
@@ -701,10 +740,12 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
         }
     }
     if (leaf >= 0) {
+        CR_DIAG_HIT(dg, DG_LEAFPH_WAVE, DG_LEAFPH_LANE);
         int32_t first = leaf >> 1, count = (leaf & 1) + 1;
         for (int32_t k = 0; k < count; k++) {
             const Prim<real>& p = prims[first + k];
             c_prim++;
+            CR_DIAG_HIT(dg, DG_PRIM_WAVE, DG_PRIM_LANE);
             real t;
             bool h;
             real g0 = p.g[0], g1 = p.g[1], g2 = p.g[2], g3 = p.g[3];
@@ -725,8 +766,7 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
     }
 }
 
-// Diagnostic build (-DCR_DIAG, scripts/diag only): per-wave phase clocks and lane-occupancy sums go to
-// counters[4..15]; the product build compiles none of it.
+// Diagnostic build: per-wave phase clocks go to counters[9..12] (regeneration, walk, shade, total).
 #ifdef CR_DIAG
 #define CR_DIAG_ONLY(...) __VA_ARGS__
 #else
@@ -786,6 +826,7 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
 
     int state = ST_NEED_PIXEL;
     uint32_t pix_i = 0, pix_j = 0;
+    uint32_t item = 0;   // sample-granular mode: the lane's current work item
     int32_t sample = 0;
     real acc_r = 0, acc_g = 0, acc_b = 0;
     // path state
@@ -800,10 +841,12 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
     ws.inv = mk<real>(0, 0, 0); ws.dd = 0; ws.best_t = 0; ws.best = -1; ws.idx = 0; ws.exact_box = false;
     const int32_t n_entries = A.n_entries;
 
-    CR_DIAG_ONLY(unsigned long long d_iter = 0, d_inner = 0, d_inner_lanes = 0, d_leaf = 0, d_leaf_lanes = 0, d_t_regen = 0, d_t_trace = 0,
-                 d_t_shade = 0, d_shade_lanes = 0, d_regen_lanes = 0, d_trace_lanes = 0; unsigned long long d_t0 = __builtin_readcyclecounter(); const unsigned long long d_begin = d_t0;)
+    Diag* dgp = nullptr;
+    CR_DIAG_ONLY(Diag dg_store; for (int i = 0; i < DG_N; i++) dg_store.v[i] = 0; dgp = &dg_store;
+                 unsigned long long d_t_regen = 0, d_t_trace = 0, d_t_shade = 0;
+                 unsigned long long d_t0 = __builtin_readcyclecounter(); const unsigned long long d_begin = d_t0;)
     for (;;) {
-        CR_DIAG_ONLY(d_iter++; d_t0 = __builtin_readcyclecounter();)
+        CR_DIAG_ONLY(if (CR_DIAG_LEADER()) dg_store.v[DG_OUTER_WAVE]++; d_t0 = __builtin_readcyclecounter();)
         // ---------------- regeneration: pixels
         uint64_t need = __ballot(state == ST_NEED_PIXEL);
         if (need && A.sg_on) {
@@ -823,6 +866,7 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
                 const uint32_t w = rank < avail ? wv_next + rank : fresh + (rank - avail);
                 if (w >= total_work) state = ST_DONE;
                 else {
+                    item = w;
                     const uint32_t group = w >> 6, in = w & 63u;
                     const uint32_t tile = group / A.sg_groups, sg = group - tile * A.sg_groups;
                     const uint32_t px = in & ((1u << A.sg_lw) - 1u), py = (in >> A.sg_lw) & ((1u << A.sg_lh) - 1u);
@@ -860,6 +904,7 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
 
         // ---------------- regeneration: camera rays (cast_ray, ray_casting.rs:82-105)
         if (state == ST_NEED_SAMPLE) {
+            CR_DIAG_HIT(dgp, DG_REGEN_WAVE, DG_REGEN_LANE);
             camera_ray<real, ANIM>(A, pix_i, pix_j, sample, rng, ro, rd, rtime);
             depth_left = A.max_depth; stack_n = 0;
             state = ST_TRACE;
@@ -867,7 +912,6 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
 
         CR_DIAG_ONLY({ unsigned long long t = __builtin_readcyclecounter(); d_t_regen += t - d_t0; d_t0 = t; })
         // ---------------- closest hit (Hittables::hit on the BVH root, interval (0.001, inf))
-        CR_DIAG_ONLY(d_regen_lanes += __popcll(__ballot(depth_left == A.max_depth && state == ST_TRACE)); d_trace_lanes += __popcll(__ballot(state == ST_TRACE));)
         V3<real> col = mk<real>(0, 0, 0);   // colour returned by the innermost ray_color call
         bool finished = false;
         if (state == ST_TRACE) {
@@ -884,8 +928,7 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
         // shading changes.
         if (__ballot(state == ST_WALK)) {
             for (;;) {
-                CR_DIAG_ONLY(d_leaf++;)
-                walk_round<real, RES, ANIM, ORD>(A, lds_entries, prims, ro, rd, rtime, ws, state == ST_WALK, A.walk_round_steps, c_node, c_prim);
+                walk_round<real, RES, ANIM, ORD>(A, lds_entries, prims, ro, rd, rtime, ws, state == ST_WALK, A.walk_round_steps, c_node, c_prim, dgp);
                 if (state == ST_WALK && ws.idx >= n_entries) state = ST_SHADE;
                 const uint64_t walking = __ballot(state == ST_WALK);
                 if (!walking || 64u - (uint32_t)__popcll(walking) >= A.walk_exit_lanes) break;
@@ -893,18 +936,17 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
         }
         const bool tracing = (state == ST_SHADE);
 
-        CR_DIAG_ONLY({ unsigned long long t = __builtin_readcyclecounter(); d_t_trace += t - d_t0; d_t0 = t; d_shade_lanes += __popcll(__ballot(tracing)); })
+        CR_DIAG_ONLY({ unsigned long long t = __builtin_readcyclecounter(); d_t_trace += t - d_t0; d_t0 = t; })
         // ---------------- shade
         if (tracing) {
             finished = shade<real, ANIM>(A, prims, mats, texs, ro, rd, rtime, rng, depth_left, stack_n, ws.best_t, ws.best,
-                                         A.n_threads, gtid, c_tex, col);
+                                         A.n_threads, gtid, c_tex, col, dgp);
             state = ST_TRACE;   // scattered: a fresh ray to walk (overwritten below when the path finished)
         }
 
         // ---------------- sample / pixel completion (average_samples, ray_casting.rs:154-173)
         if (finished && A.sg_on) {   // the ordered sum happens in sg_finalize_kernel
-            const size_t npix = (size_t)cam.W * (size_t)cam.H;
-            real* o = A.sample_buf + ((size_t)(sample - A.sample_begin) * npix + (size_t)pix_j * (size_t)cam.W + pix_i) * 3;
+            real* o = A.sample_buf + (size_t)item * 3;
             o[0] = col.x; o[1] = col.y; o[2] = col.z;
             state = ST_NEED_PIXEL;
         } else if (finished) {
@@ -931,13 +973,13 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
     };
     unsigned long long s0 = wave_sum(c_seg), s1 = wave_sum(c_node), s2 = wave_sum(c_prim), s3 = wave_sum(c_tex);
     CR_DIAG_ONLY(
-        unsigned long long w_inner = wave_sum(d_inner), w_inner_w = wave_sum(d_inner_lanes), w_leaf = wave_sum(d_leaf), w_leaf_w = wave_sum(d_leaf_lanes);
-        if (lane == 0) {
+        {
             unsigned long long* c = (unsigned long long*)A.counters;
-            atomicAdd(&c[4], d_iter); atomicAdd(&c[5], w_inner); atomicAdd(&c[6], w_inner_w >> 16); atomicAdd(&c[7], w_leaf);
-            atomicAdd(&c[8], w_leaf_w >> 16); atomicAdd(&c[9], d_t_regen); atomicAdd(&c[10], d_t_trace); atomicAdd(&c[11], d_t_shade);
-            atomicAdd(&c[12], __builtin_readcyclecounter() - d_begin); atomicAdd(&c[13], d_shade_lanes); atomicAdd(&c[14], d_trace_lanes);
-            atomicAdd(&c[15], d_regen_lanes);
+            for (int i = 0; i < DG_N; i++) { unsigned long long w = wave_sum(dg_store.v[i]); if (lane == 0) atomicAdd(&c[16 + i], w); }
+            if (lane == 0) {
+                atomicAdd(&c[9], d_t_regen); atomicAdd(&c[10], d_t_trace); atomicAdd(&c[11], d_t_shade);
+                atomicAdd(&c[12], __builtin_readcyclecounter() - d_begin);
+            }
         })
     if (lane == 0) {
         atomicAdd((unsigned long long*)&A.counters[0], s0);
@@ -969,13 +1011,23 @@ pathtrace_kernel_latency(const KernelArgs<real> A) {
 template <typename real>
 __global__ void __launch_bounds__(256) sg_finalize_kernel(const KernelArgs<real> A, real* acc, int32_t batch_samples, int32_t first_batch,
                                                           int32_t last_batch) {
-    const size_t npix = (size_t)A.cam.W * A.cam.H;
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npix) return;
+    // one thread per pixel, threads numbered tile by tile (the pixels of a tile are consecutive threads), so the
+    // reads of a sample group are contiguous across the tile's threads
+    const uint32_t tile_px = 1u << (A.sg_lw + A.sg_lh);
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tile = (uint32_t)(t >> (A.sg_lw + A.sg_lh)), in_px = (uint32_t)t & (tile_px - 1u);
+    if (tile >= A.tiles_x * A.tiles_y) return;
+    const uint32_t pi = ((tile % A.tiles_x) << A.sg_lw) + (in_px & ((1u << A.sg_lw) - 1u));
+    const uint32_t pj = ((tile / A.tiles_x) << A.sg_lh) + (in_px >> A.sg_lw);
+    if (pi >= (uint32_t)A.cam.W || pj >= (uint32_t)A.cam.H) return;
+    const size_t p = (size_t)pj * (size_t)A.cam.W + pi;
+    const uint32_t ns = 64u >> (A.sg_lw + A.sg_lh);
     real r = 0, g = 0, b = 0;
     if (!first_batch) { r = acc[3 * p]; g = acc[3 * p + 1]; b = acc[3 * p + 2]; }
     for (int32_t s = 0; s < batch_samples; s++) {
-        const real* c = A.sample_buf + ((size_t)s * npix + p) * 3;
+        const uint32_t sg = (uint32_t)s / ns, ds = (uint32_t)s - sg * ns;
+        const size_t item = ((size_t)tile * A.sg_groups + sg) * 64u + ((size_t)ds << (A.sg_lw + A.sg_lh)) + in_px;
+        const real* c = A.sample_buf + item * 3;
         r += c[0]; g += c[1]; b += c[2];
     }
     if (last_batch) {

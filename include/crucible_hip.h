@@ -285,7 +285,7 @@ CR_API int32_t cr_upload_scene(CrHandle* h, const CrSceneDesc* scene);
  * (then it synchronises to fill the stats).
  * Device memory: besides the scene the handle keeps a per-path attenuation stack (3*max_depth reals per
  * resident lane, ~150 MB at depth 50) and a per-sample colour buffer of image_width*image_height*3 reals per
- * sample index, up to 16 GiB (CRUCIBLE_SAMPLE_BUF_MB; a render that needs more runs as consecutive sample
+ * sample index, up to 40 GiB (CRUCIBLE_SAMPLE_BUF_MB; a render that needs more runs as consecutive sample
  * batches, CRUCIBLE_SAMPLE_GRANULAR=0 avoids the buffer at a large cost in speed).  The buffers are
  * grown on demand, reused by later renders and freed by cr_destroy. */
 CR_API int32_t cr_render_device(CrHandle* h, const CrCameraDesc* cam, const CrRenderParams* params,

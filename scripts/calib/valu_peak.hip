@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256) loop_kernel(unsigned long long* cycles, f
 #define OP_ADD_F32(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[i]) : "v"(c));
 #define OP_MAX_F32(i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(f[i]) : "v"(c));
 #define OP_MAX3_F32(i) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(c), "v"(b));
-#define OP_CND(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(u[(i + 1) & 7]) : "vcc");
+#define OP_CND(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(threadIdx.x));
 #define OP_ADD_U32(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
 #define OP_ADD_F64(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[i]) : "v"(cd));
 #define OP_MUL_F64(i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[i]) : "v"(bd));
@@ -71,8 +71,13 @@ template <int KIND> void run(int n_cus, unsigned long long* d_cyc, float* d_sink
         const int block = 256, grid = n_cus * wps;   // 256 threads = 4 waves = one wave per SIMD per resident block
         loop_kernel<KIND><<<grid, block>>>(d_cyc, d_sink, 16);
         hipDeviceSynchronize();
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
         loop_kernel<KIND><<<grid, block>>>(d_cyc, d_sink, iters);
+        hipEventRecord(e1);
         hipDeviceSynchronize();
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        hipEventDestroy(e0); hipEventDestroy(e1);
         const int n_waves = grid * 4;
         std::vector<unsigned long long> h(n_waves);
         hipMemcpy(h.data(), d_cyc, n_waves * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -80,7 +85,9 @@ template <int KIND> void run(int n_cus, unsigned long long* d_cyc, float* d_sink
         for (auto v : h) sum += (double)v;
         const double per_wave = sum / n_waves;                       // cycles one wave needed for iters * 32 instructions
         const double cyc_per_instr_simd = per_wave / (iters * 32.0) / wps;   // wps waves share the SIMD
-        printf("  %d w/SIMD: %5.2f", wps, cyc_per_instr_simd);
+        // the same rate from the wall clock (HIP events): ns per instruction per SIMD, and the implied tick rate
+        const double ns_per_instr_simd = (double)ms * 1e6 / (iters * 32.0) / wps;
+        printf("  %d w/SIMD: %5.2f cyc %5.3f ns (%.2f GHz)", wps, cyc_per_instr_simd, ns_per_instr_simd, cyc_per_instr_simd / ns_per_instr_simd);
         if (js) fprintf(js, "%s\"%d\": %.3f", col++ ? ", " : "", wps, cyc_per_instr_simd);
     }
     printf("   cycles per wave64 instruction per SIMD\n");

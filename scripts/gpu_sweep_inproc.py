@@ -33,5 +33,7 @@ for rnd, ex in combos:
         r.render_device(cam, out.data_ptr(), seed=0xC0FFEE, real_type=rt)
         best = min(best, r.last_kernel_ms())
     n = cam.image_width * cam.image_height * spp
-    print(f"{workload} {real} round={rnd} exit={ex}: {best:.2f} ms  {n / best / 1e3:.1f} Msamples/s", flush=True)
+    st = r.render_device(cam, out.data_ptr(), seed=0xC0FFEE, real_type=rt, want_stats=True)   # counters (and [diag] lines of a diagnostic build)
+    print(f"{workload} {real} round={rnd} exit={ex}: {best:.2f} ms  {n / best / 1e3:.1f} Msamples/s  "
+          f"seg/sample {st['segments'] / st['samples']:.3f} node/seg {st['node_tests'] / st['segments']:.2f} prim/seg {st['prim_tests'] / st['segments']:.3f}", flush=True)
     r.close()
