@@ -450,13 +450,120 @@ CR_D V3<real> image_lookup(const ImageRef* images, const uint32_t* texels, int i
     return mk<real>((real)(px & 255u) / real(255), (real)((px >> 8) & 255u) / real(255), (real)((px >> 16) & 255u) / real(255));
 }
 
-// device math the sky / sphere-uv lookups need (ocml); kept in one place
-CR_D float r_atan2(float y, float x) { return atan2f(y, x); }
-CR_D double r_atan2(double y, double x) { return atan2(y, x); }
-CR_D float r_asin(float x) { return asinf(x); }
-CR_D double r_asin(double x) { return asin(x); }
-CR_D float r_acos(float x) { return acosf(x); }
-CR_D double r_acos(double x) { return acos(x); }
+// ------------------------------------------------------------------ software atan2 / asin / acos
+// The reference calls f64::atan2 / asin / acos (ray_casting.rs:137-138, sphere.rs:42-43): the platform libm, whose
+// last-ulp behaviour differs between glibc and the device's ocml -- enough to move a texel index.  The library and
+// the oracle therefore evaluate ONE documented algorithm with +, -, *, /, sqrt only (DESIGN.md "software
+// trigonometry"; coefficients from scripts/gen_trig_coeffs.py), which makes the image-texture and spherical-sky
+// scenes bit-exact:
+//   atan:  fdlibm's argument reduction at 7/16, 11/16, 19/16, 39/16, then atan(t) = t - t*(z*A(z)), z = t*t,
+//          result = hi - ((t*(z*A(z)) - lo) - t) with hi + lo = atan(0.5), pi/4, atan(1.5), pi/2;
+//   asin:  |x| < 0.5: x + x*(z*S(z)), z = x*x; else pi/2 - 2*asin(sqrt((1 - |x|)/2)); acos likewise;
+//   A, S:  Horner from the highest coefficient, multiply then add.  Within 1-3 ulp of the correctly rounded value.
+template <typename real> struct TrigK;
+template <> struct TrigK<double> {
+    static CR_HD double A(double z) {
+        double p = -0x1.e4167464d3de8p-7;
+        p = p * z + 0x1.0f62bba6a2558p-5; p = p * z + -0x1.7001816fd063fp-5; p = p * z + 0x1.ab59b417b2d3fp-5;
+        p = p * z + -0x1.e170800a46210p-5; p = p * z + 0x1.110c9ce7b0572p-4; p = p * z + -0x1.3b1375ce5bdc6p-4;
+        p = p * z + 0x1.745d154c84f7ap-4; p = p * z + -0x1.c71c71bd2b8bcp-4; p = p * z + 0x1.2492492485503p-3;
+        p = p * z + -0x1.99999999998c5p-3; p = p * z + 0x1.5555555555555p-2;
+        return p;
+    }
+    static CR_HD double S(double z) {
+        double p = 0x1.06c051be25377p-5;
+        p = p * z + -0x1.dfdd83264a978p-6; p = p * z + 0x1.b20b9dc229eb5p-6; p = p * z + -0x1.641b6703bb104p-9;
+        p = p * z + 0x1.1e6dafec868fcp-7; p = p * z + 0x1.c232290f7ae75p-8; p = p * z + 0x1.14f7ebcffc822p-7;
+        p = p * z + 0x1.3fa92e3923959p-7; p = p * z + 0x1.7a8b73dc1b007p-7; p = p * z + 0x1.c99964e8e2de8p-7;
+        p = p * z + 0x1.1c4ec5dfe81d9p-6; p = p * z + 0x1.6e8ba2e2f8089p-6; p = p * z + 0x1.f1c71c71dc217p-6;
+        p = p * z + 0x1.6db6db6db6c75p-5; p = p * z + 0x1.3333333333334p-4; p = p * z + 0x1.5555555555555p-3;
+        return p;
+    }
+    static constexpr double at_hi0 = 0x1.dac670561bb4fp-2, at_lo0 = 0x1.a2b7f222f65e2p-56;   // atan(0.5)
+    static constexpr double at_hi1 = 0x1.921fb54442d18p-1, at_lo1 = 0x1.1a62633145c07p-55;   // pi/4
+    static constexpr double at_hi2 = 0x1.f730bd281f69bp-1, at_lo2 = 0x1.007887af0cbbdp-56;   // atan(1.5)
+    static constexpr double pio2_hi = 0x1.921fb54442d18p+0, pio2_lo = 0x1.1a62633145c07p-54;
+    static constexpr double pi_hi = 0x1.921fb54442d18p+1, pi_lo = 0x1.1a62633145c07p-53;
+};
+template <> struct TrigK<float> {
+    static CR_HD float A(float z) {
+        float p = -0x1.8b0b06p-5f;
+        p = p * z + 0x1.5d79d8p-4f; p = p * z + -0x1.c4f1ecp-4f; p = p * z + 0x1.248626p-3f; p = p * z + -0x1.999968p-3f;
+        p = p * z + 0x1.555556p-2f;
+        return p;
+    }
+    static CR_HD float S(float z) {
+        float p = 0x1.fb7ca4p-6f;
+        p = p * z + 0x1.5a80ap-7f; p = p * z + 0x1.82db24p-6f; p = p * z + 0x1.efedf8p-6f; p = p * z + 0x1.6dc0fp-5f;
+        p = p * z + 0x1.33331ep-4f; p = p * z + 0x1.555556p-3f;
+        return p;
+    }
+    static constexpr float at_hi0 = 0.46364760398864746f, at_lo0 = 5.01215868808913e-09f;
+    static constexpr float at_hi1 = 0.7853981852531433f, at_lo1 = -2.1855694143368964e-08f;
+    static constexpr float at_hi2 = 0.9827937483787537f, at_lo2 = -2.5131424052915463e-08f;
+    static constexpr float pio2_hi = 1.5707963705062866f, pio2_lo = -4.371138828673793e-08f;
+    static constexpr float pi_hi = 3.1415927410125732f, pi_lo = -8.742277657347586e-08f;
+};
+// atan(x) for x >= 0 (also +inf; NaN propagates)
+template <typename real> CR_HD real soft_atan_pos(real x) {
+    using K = TrigK<real>;
+    real t, hi = real(0), lo = real(0);
+    bool reduced = true;
+    if (x < real(0.4375)) { t = x; reduced = false; }
+    else if (x < real(0.6875)) { t = (real(2) * x - real(1)) / (real(2) + x); hi = K::at_hi0; lo = K::at_lo0; }
+    else if (x < real(1.1875)) { t = (x - real(1)) / (x + real(1)); hi = K::at_hi1; lo = K::at_lo1; }
+    else if (x < real(2.4375)) { t = (x - real(1.5)) / (real(1) + real(1.5) * x); hi = K::at_hi2; lo = K::at_lo2; }
+    else { t = real(-1) / x; hi = K::pio2_hi; lo = K::pio2_lo; }
+    const real z = t * t;
+    const real s = t * (z * K::A(z));
+    return reduced ? hi - ((s - lo) - t) : t - s;
+}
+template <typename real> CR_HD real soft_atan2(real y, real x) {
+    using K = TrigK<real>;
+    if (x != x || y != y) return x + y;
+    const bool sx = __builtin_signbit(x), sy = __builtin_signbit(y);
+    const real inf = r_inf(real(0));
+    if (y == real(0)) return sx ? (sy ? -K::pi_hi : K::pi_hi) : y;
+    if (x == real(0)) return sy ? -K::pio2_hi : K::pio2_hi;
+    const real ax = r_abs(x), ay = r_abs(y);
+    if (ax == inf) {
+        if (ay == inf) { const real q = sx ? real(3) * K::at_hi1 : K::at_hi1; return sy ? -q : q; }
+        const real q = sx ? K::pi_hi : real(0);
+        return sy ? -q : q;
+    }
+    if (ay == inf) return sy ? -K::pio2_hi : K::pio2_hi;
+    const real z = soft_atan_pos(ay / ax);
+    const real res = sx ? K::pi_hi - (z - K::pi_lo) : z;
+    return sy ? -res : res;
+}
+template <typename real> CR_HD real soft_asin(real x) {
+    using K = TrigK<real>;
+    const real ax = r_abs(x);
+    if (ax < real(0.5)) { const real z = x * x; return x + x * (z * K::S(z)); }
+    if (!(ax <= real(1))) return (x - x) / (x - x);
+    const real t = (real(1) - ax) * real(0.5);
+    const real s = r_sqrt(t);
+    const real res = K::pio2_hi - (real(2) * (s + s * (t * K::S(t))) - K::pio2_lo);
+    return x < real(0) ? -res : res;
+}
+template <typename real> CR_HD real soft_acos(real x) {
+    using K = TrigK<real>;
+    const real ax = r_abs(x);
+    if (ax < real(0.5)) { const real z = x * x; return K::pio2_hi - (x - (K::pio2_lo - x * (z * K::S(z)))); }
+    if (!(ax <= real(1))) return (x - x) / (x - x);
+    if (x < real(0)) {
+        const real t = (real(1) + x) * real(0.5);
+        const real s = r_sqrt(t);
+        const real w = (t * K::S(t)) * s - K::pio2_lo;
+        return K::pi_hi - real(2) * (s + w);
+    }
+    const real t = (real(1) - x) * real(0.5);
+    const real s = r_sqrt(t);
+    return real(2) * (s + s * (t * K::S(t)));
+}
+template <typename real> CR_D real r_atan2(real y, real x) { return soft_atan2(y, x); }
+template <typename real> CR_D real r_asin(real x) { return soft_asin(x); }
+template <typename real> CR_D real r_acos(real x) { return soft_acos(x); }
 
 // Camera::cast_ray's per-sample ray (ray_casting.rs:82-105): seeds the sample's RNG stream and draws
 // time, pixel offset and (with defocus) the lens point, in the reference's order.

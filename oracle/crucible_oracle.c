@@ -63,9 +63,9 @@ typedef float real;
 #define R_SQRT sqrtf
 #define R_FABS fabsf
 #define R_FLOOR floorf
-#define R_ATAN2 atan2f
-#define R_ASIN asinf
-#define R_ACOS acosf
+#define LIBM_ATAN2 atan2f
+#define LIBM_ASIN asinf
+#define LIBM_ACOS acosf
 #define R_FMIN fminf
 #define R_EPSILON FLT_EPSILON
 #define R_INF HUGE_VALF
@@ -75,9 +75,9 @@ typedef double real;
 #define R_SQRT sqrt
 #define R_FABS fabs
 #define R_FLOOR floor
-#define R_ATAN2 atan2
-#define R_ASIN asin
-#define R_ACOS acos
+#define LIBM_ATAN2 atan2
+#define LIBM_ASIN asin
+#define LIBM_ACOS acos
 #define R_FMIN fmin
 #define R_EPSILON DBL_EPSILON
 #define R_INF HUGE_VAL
@@ -88,6 +88,110 @@ typedef double real;
 
 #define R(x) ((real)(x))
 static const real R_PI = (real)3.14159265358979323846264338327950288; /* std::f64::consts::PI */
+
+/* ------------------------------------------------------------------ atan2 / asin / acos
+ * The reference calls f64::atan2 / asin / acos (ray_casting.rs:137-138, sphere.rs:42-43), i.e. the platform libm.
+ * libm results are not bit-identical across platforms (glibc here, ocml on the device), and a last-ulp difference
+ * can move a texel index.  Like the random generator, the build therefore DEFINES these three functions (DESIGN.md,
+ * "software trigonometry") and this oracle and the device library each implement that definition from its text:
+ *
+ *   atan(x), x >= 0:   x < 7/16: t = x;  < 11/16: t = (2x-1)/(2+x), c = atan(.5);  < 19/16: t = (x-1)/(x+1), c = pi/4;
+ *                      < 39/16: t = (x-1.5)/(1+1.5x), c = atan(1.5);  else t = -1/x, c = pi/2
+ *                      z = t*t; s = t*(z*A(z));  result = t - s   or   c_hi - ((s - c_lo) - t)
+ *   atan2(y, x):       quadrant fix-up of atan(|y|/|x|) as fdlibm's e_atan2.c does (pi - (z - pi_lo) for x < 0)
+ *   asin(x):           |x| < .5: x + x*(z*S(z)), z = x*x;  else t = (1-|x|)/2, s = sqrt(t):
+ *                      pio2_hi - (2*(s + s*(t*S(t))) - pio2_lo), sign of x
+ *   acos(x):           |x| < .5: pio2_hi - (x - (pio2_lo - x*(z*S(z))));  x <= -.5: t = (1+x)/2: pi_hi - 2*(s + ((t*S(t))*s - pio2_lo));
+ *                      x >= .5: t = (1-x)/2: 2*(s + s*(t*S(t)))
+ *   A, S:              polynomials (scripts/gen_trig_coeffs.py), Horner from the highest coefficient, multiply then add.
+ *
+ * oracle_set_libm(1) switches to glibc's functions instead -- what the Rust binary would call on this box -- so the
+ * tests can bound the difference (a few ulp per call; texel indices agree except on isolated pixels). */
+static int g_use_libm = 0;
+#if defined(CR_ORACLE_F64)
+static const real TRIG_A[12] = {0x1.5555555555555p-2, -0x1.99999999998c5p-3, 0x1.2492492485503p-3, -0x1.c71c71bd2b8bcp-4,
+                                0x1.745d154c84f7ap-4, -0x1.3b1375ce5bdc6p-4, 0x1.110c9ce7b0572p-4, -0x1.e170800a46210p-5,
+                                0x1.ab59b417b2d3fp-5, -0x1.7001816fd063fp-5, 0x1.0f62bba6a2558p-5, -0x1.e4167464d3de8p-7};
+static const real TRIG_S[16] = {0x1.5555555555555p-3, 0x1.3333333333334p-4, 0x1.6db6db6db6c75p-5, 0x1.f1c71c71dc217p-6,
+                                0x1.6e8ba2e2f8089p-6, 0x1.1c4ec5dfe81d9p-6, 0x1.c99964e8e2de8p-7, 0x1.7a8b73dc1b007p-7,
+                                0x1.3fa92e3923959p-7, 0x1.14f7ebcffc822p-7, 0x1.c232290f7ae75p-8, 0x1.1e6dafec868fcp-7,
+                                -0x1.641b6703bb104p-9, 0x1.b20b9dc229eb5p-6, -0x1.dfdd83264a978p-6, 0x1.06c051be25377p-5};
+#define TRIG_NA 12
+#define TRIG_NS 16
+static const real AT_HI[4] = {0x1.dac670561bb4fp-2, 0x1.921fb54442d18p-1, 0x1.f730bd281f69bp-1, 0x1.921fb54442d18p+0};
+static const real AT_LO[4] = {0x1.a2b7f222f65e2p-56, 0x1.1a62633145c07p-55, 0x1.007887af0cbbdp-56, 0x1.1a62633145c07p-54};
+static const real PI_HI = 0x1.921fb54442d18p+1, PI_LO = 0x1.1a62633145c07p-53;
+#else
+static const real TRIG_A[6] = {0x1.555556p-2f, -0x1.999968p-3f, 0x1.248626p-3f, -0x1.c4f1ecp-4f, 0x1.5d79d8p-4f, -0x1.8b0b06p-5f};
+static const real TRIG_S[7] = {0x1.555556p-3f, 0x1.33331ep-4f, 0x1.6dc0fp-5f, 0x1.efedf8p-6f, 0x1.82db24p-6f, 0x1.5a80ap-7f, 0x1.fb7ca4p-6f};
+#define TRIG_NA 6
+#define TRIG_NS 7
+static const real AT_HI[4] = {0.46364760398864746f, 0.7853981852531433f, 0.9827937483787537f, 1.5707963705062866f};
+static const real AT_LO[4] = {5.01215868808913e-09f, -2.1855694143368964e-08f, -2.5131424052915463e-08f, -4.371138828673793e-08f};
+static const real PI_HI = 3.1415927410125732f, PI_LO = -8.742277657347586e-08f;
+#endif
+static real trig_poly(const real* c, int n, real z) {
+    real p = c[n - 1];
+    for (int i = n - 2; i >= 0; i--) p = p * z + c[i];
+    return p;
+}
+static real def_atan_pos(real x) {
+    int id;
+    real t;
+    if (x < R(0.4375)) { id = -1; t = x; }
+    else if (x < R(0.6875)) { id = 0; t = (R(2.0) * x - R(1.0)) / (R(2.0) + x); }
+    else if (x < R(1.1875)) { id = 1; t = (x - R(1.0)) / (x + R(1.0)); }
+    else if (x < R(2.4375)) { id = 2; t = (x - R(1.5)) / (R(1.0) + R(1.5) * x); }
+    else { id = 3; t = R(-1.0) / x; }
+    real z = t * t;
+    real s = t * (z * trig_poly(TRIG_A, TRIG_NA, z));
+    if (id < 0) return t - s;
+    return AT_HI[id] - ((s - AT_LO[id]) - t);
+}
+static real def_atan2(real y, real x) {
+    if (x != x || y != y) return x + y;
+    int sx = signbit(x) != 0, sy = signbit(y) != 0;
+    real pio2 = AT_HI[3];
+    if (y == R(0.0)) return sx ? (sy ? -PI_HI : PI_HI) : y;
+    if (x == R(0.0)) return sy ? -pio2 : pio2;
+    real ax = R_FABS(x), ay = R_FABS(y);
+    if (ax == R_INF) {
+        real q;
+        if (ay == R_INF) q = sx ? R(3.0) * AT_HI[1] : AT_HI[1];
+        else q = sx ? PI_HI : R(0.0);
+        return sy ? -q : q;
+    }
+    if (ay == R_INF) return sy ? -pio2 : pio2;
+    real z = def_atan_pos(ay / ax);
+    real res = sx ? PI_HI - (z - PI_LO) : z;
+    return sy ? -res : res;
+}
+static real def_asin(real x) {
+    real ax = R_FABS(x);
+    if (ax < R(0.5)) { real z = x * x; return x + x * (z * trig_poly(TRIG_S, TRIG_NS, z)); }
+    if (!(ax <= R(1.0))) return (x - x) / (x - x);
+    real t = (R(1.0) - ax) * R(0.5);
+    real s = R_SQRT(t);
+    real res = AT_HI[3] - (R(2.0) * (s + s * (t * trig_poly(TRIG_S, TRIG_NS, t))) - AT_LO[3]);
+    return x < R(0.0) ? -res : res;
+}
+static real def_acos(real x) {
+    real ax = R_FABS(x);
+    if (ax < R(0.5)) { real z = x * x; return AT_HI[3] - (x - (AT_LO[3] - x * (z * trig_poly(TRIG_S, TRIG_NS, z)))); }
+    if (!(ax <= R(1.0))) return (x - x) / (x - x);
+    if (x < R(0.0)) {
+        real t = (R(1.0) + x) * R(0.5);
+        real s = R_SQRT(t);
+        real w = (t * trig_poly(TRIG_S, TRIG_NS, t)) * s - AT_LO[3];
+        return PI_HI - R(2.0) * (s + w);
+    }
+    real t = (R(1.0) - x) * R(0.5);
+    real s = R_SQRT(t);
+    return R(2.0) * (s + s * (t * trig_poly(TRIG_S, TRIG_NS, t)));
+}
+static real R_ATAN2(real y, real x) { return g_use_libm ? LIBM_ATAN2(y, x) : def_atan2(y, x); }
+static real R_ASIN(real x) { return g_use_libm ? LIBM_ASIN(x) : def_asin(x); }
+static real R_ACOS(real x) { return g_use_libm ? LIBM_ACOS(x) : def_acos(x); }
 
 /* ------------------------------------------------------------------ utils.rs */
 
@@ -842,6 +946,15 @@ EXPORT void oracle_scene_destroy(Scene* sc) {
     free(sc->images); free(sc->prims); free(sc->materials); free(sc->textures); free(sc->keys); free(sc->pool);
     free(sc->empty_list.objs);
     free(sc);
+}
+
+EXPORT void oracle_set_libm(int32_t use_glibc) { g_use_libm = use_glibc != 0; }
+EXPORT void oracle_trig(const real* in, int32_t n, real* atan2_out, real* asin_out, real* acos_out) {   /* in: n pairs (y, x) */
+    for (int32_t i = 0; i < n; i++) {
+        atan2_out[i] = R_ATAN2(in[2 * i], in[2 * i + 1]);
+        asin_out[i] = R_ASIN(in[2 * i]);
+        acos_out[i] = R_ACOS(in[2 * i]);
+    }
 }
 
 EXPORT Scene* oracle_scene_create(const CrSceneDesc* d) {

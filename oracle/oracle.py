@@ -78,6 +78,10 @@ class Oracle:
         L.oracle_set_tree.restype = C.c_int32
         L.oracle_use_list.argtypes = [P]
         L.oracle_use_list.restype = None
+        L.oracle_set_libm.argtypes = [C.c_int32]
+        L.oracle_set_libm.restype = None
+        L.oracle_trig.argtypes = [P, C.c_int32, P, P, P]
+        L.oracle_trig.restype = None
 
     # ---- helpers
     def arr(self, x):
@@ -91,6 +95,17 @@ class Oracle:
         out = np.zeros(n_out, dtype=self.np_real)
         getattr(self.lib, name)(*[self._p(i) for i in ins], self._p(out))
         return out
+
+    # ---- atan2 / asin / acos: the build's defined functions (default) or glibc's (what the Rust binary would call here)
+    def set_libm(self, use_glibc):
+        self.lib.oracle_set_libm(1 if use_glibc else 0)
+
+    def trig(self, y, x):
+        """(atan2(y, x), asin(y), acos(y)) elementwise with the currently selected implementation."""
+        inp = self.arr(np.stack([np.asarray(y), np.asarray(x)], axis=1))
+        outs = [np.zeros(len(inp), dtype=self.np_real) for _ in range(3)]
+        self.lib.oracle_trig(self._p(inp), len(inp), *[self._p(o) for o in outs])
+        return outs
 
     # ---- scene
     def scene_create(self, flat):

@@ -1,9 +1,9 @@
 """Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle and the
-committed golden vectors.  Bar: bit-exact images and equal work counters wherever the path uses
-only IEEE +,-,*,/,sqrt,floor (book1, checker, solid, default sky, triangles, keyframes); for scenes
-that go through acos/atan2/asin (sphere u,v for image textures, spherical sky) the device's libm
-(ocml) may differ from glibc in the last ulp, which can move a texel index: there the bar is
-north_star's per-channel tolerance of 1e-4 on at least 99.9% of pixels, and it is written below.
+committed golden vectors.  Bar: bit-exact images and equal work counters EVERYWHERE.  The path uses
+only IEEE +,-,*,/,sqrt,floor; acos/atan2/asin (sphere u,v for image textures, spherical sky) are the
+build's own defined functions, evaluated with the same operations by the oracle and the device
+(DESIGN.md "software trigonometry"), so no scene needs a tolerance.  north_star's per-channel
+tolerance of 1e-4 is used only where two DIFFERENT arithmetics are compared (f32 mode vs the f64 oracle).
 """
 import ctypes as C
 import os
@@ -38,12 +38,6 @@ def assert_exact(img, st, ref, rst):
         assert st[k] == rst[k], (k, st[k], rst[k])
 
 
-def assert_close(img, ref, frac=0.999):
-    d = np.abs(img.astype(np.float64) - ref.astype(np.float64)).max(axis=2)
-    ok = (d <= TOL).mean()
-    assert ok >= frac, f"only {ok:.5f} of pixels within {TOL}; max |d| = {d.max()}"
-
-
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
 @pytest.mark.parametrize("name,build", [
     ("book1_64x36_spp4", lambda: book1_end_scene(1, scene_seed=1, image_width=64, samples=4)),
@@ -63,15 +57,11 @@ def test_golden_images_bit_exact(renderer, rt, tag, name, build):
     ("mixed_nosky_40x22_spp3", lambda: scenes.mixed_scene(40, 3, sky=False)),
 ])
 def test_golden_images_mixed(renderer, rt, tag, name, build):
-    """Triangles, image textures, spherical sky, keyframes: within 1e-4 (libm carve-out, see module doc)."""
+    """Triangles, image textures, spherical sky, keyframes: bit-exact against the committed goldens."""
     gold = np.load(os.path.join(GOLD, f"images_{tag}.npz"))
     img, st = gpu_render(renderer, build(), rt)
-    assert_close(img, gold[name])
-    exact_px = (img == gold[name]).all(axis=2).mean()
-    assert exact_px > 0.98, exact_px
-    ref = list(gold[name + "_stats"])
-    got = [st[k] for k in COUNTERS]
-    assert all(abs(int(g) - int(r)) <= 0.002 * int(r) + 4 for g, r in zip(got, ref)), (got, ref)
+    assert np.array_equal(img, gold[name]), (img != gold[name]).any(axis=2).sum()
+    assert [st[k] for k in COUNTERS] == list(gold[name + "_stats"])
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
@@ -211,8 +201,7 @@ def test_teapot_with_environment_map(renderer, oracles, rt, tag):
     img, st = gpu_render(renderer, sc, rt)
     ref, rst = oracles[rt].render_image(sc, seed=SEED)
     assert st["scene_in_lds"] == 2 and st["bvh_entries"] == rst["bvh_entries"] == 8191
-    assert_close(img, ref)
-    assert (img == ref).all(axis=2).mean() > 0.98
+    assert_exact(img, st, ref, rst)
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
@@ -269,16 +258,15 @@ def test_alternative_schedules_are_bit_identical(oracles, monkeypatch, rt, tag, 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
 def test_earth_demo_scene(renderer, oracles, rt, tag):
-    """demo_images.rs:202-221: a globe with the earthmap.jpg image texture (sphere u,v through acos/atan2, so the
-    libm carve-out applies) under the default sky."""
+    """demo_images.rs:202-221: a globe with the earthmap.jpg image texture (sphere u,v through acos/atan2) under
+    the default sky."""
     from crucible_amd.demo_builder import earth
     sc = earth(1, image_width=96, samples=3)
     assert sc.flatten().images[0].width == 1024 and sc.flatten().images[0].height == 512
     img, st = gpu_render(renderer, sc, rt)
     ref, rst = oracles[rt].render_image(sc, seed=SEED)
-    assert st["texel_fetches"] > 0 and abs(int(st["texel_fetches"]) - int(rst["texel_fetches"])) <= 4
-    assert_close(img, ref)
-    assert (img == ref).all(axis=2).mean() > 0.98
+    assert st["texel_fetches"] > 0
+    assert_exact(img, st, ref, rst)
 
 
 def test_device_output_and_async_path(renderer):
@@ -388,7 +376,7 @@ def test_render_movie_frames_match_oracle(oracles, tmp_path):
         lines = open(os.path.join(stem, "artifacts", name)).read().split("\n")
         got = np.array([[int(x) for x in l.split()] for l in lines[3:3 + 40 * 22]], dtype=np.int64)
         exp = (255.0 * np.sqrt(ref)).astype(np.int64).reshape(-1, 3)
-        assert (np.abs(got - exp) <= 1).all() and (got == exp).mean() > 0.995     # spherical sky: libm carve-out
+        assert np.array_equal(got, exp)
         assert prev is None or not np.array_equal(prev, got)                       # the camera moved
         prev = got
     with pytest.raises(FileExistsError):
@@ -561,3 +549,22 @@ def test_checker_nesting_limit(renderer, oracles, rt, tag):
     with pytest.raises(CrucibleError) as e:
         renderer.upload_scene(sc.flatten())
     assert e.value.code == A.CR_ERR_UNSUPPORTED
+
+
+def test_f32_mode_deviation_from_the_reference_arithmetic(renderer):
+    """CR_REAL_F32 is an opt-in fast mode, NOT the reference's arithmetic (f64, utils.rs:72-74): it is bit-equal only to
+    the f32 restatement.  Against the f64 render at matched seeds it misses north_star's 1e-4 on a sizeable share of
+    pixels, because `c = |oc|^2 - r^2` (sphere.rs:80) cancels catastrophically for the r = 1000 ground sphere in f32
+    (|oc|^2 ~ 1e6 has an ulp of 0.06), which moves roots by far more than tmin = 0.001 and lets scattered rays re-hit
+    the ground: the f32 path traces ~9 % more segments.  This test pins those measured facts."""
+    sc = book1_end_scene(1, scene_seed=1, image_width=320, samples=48)
+    renderer.upload_scene(sc.flatten())
+    a, sa = renderer.render(sc.scene_cam, seed=SEED, real_type=A.CR_REAL_F64)
+    b, sb = renderer.render(sc.scene_cam, seed=SEED, real_type=A.CR_REAL_F32)
+    d = np.abs(a - b.astype(np.float64)).max(axis=2)
+    within = (d <= TOL).mean()
+    assert 0.5 < within < 0.9, within                 # measured 0.71: f32 does NOT meet the 1e-4 bar
+    assert abs((b.astype(np.float64) - a).mean()) < 2e-3     # measured -7e-4 per channel
+    assert d.mean() < 1e-2
+    ratio = sb["segments"] / sa["segments"]
+    assert 1.04 < ratio < 1.15, ratio                 # measured 1.09
