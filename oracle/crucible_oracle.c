@@ -399,7 +399,80 @@ static void timeline_parts(const Timeline* tl, real t, int side, real xyz[3], re
     }
     xyz[0] = x; xyz[1] = y; xyz[2] = z; *w = wv; *skind = sk;
 }
+/* ---- "faithful" evaluation (bench.py's second CPU baseline): the same numbers computed the way the
+ * reference computes them at EVERY hit -- each Transform is a 4x4 matrix of boxed closures (timeline/mod.rs:20-22,
+ * 64-71); get_matrix_at_time calls all 16 of them, each after its own proportion + clamp (:90-96); the active
+ * translate matrices are multiplied together, then with the scale matrix, then with (0,0,0,1) (:233-263), in
+ * nalgebra's accumulation order.  oracle_set_faithful(1) also enables the dead update_bb calls of BVHWrapper::hit
+ * (bvhwrapper.rs:104-106), the reference-count traffic of HitRecord's material clones (objects/mod.rs:53,101-103),
+ * the per-thread deep clone of the world (cpu_threading.rs:44) and the mutex around every pixel hand-out (:88).
+ * Results are bit-identical to the direct evaluation (tests/test_oracle_properties.py). */
+static int g_faithful = 0;
+typedef struct { real a, b; } ClosureEnv;
+typedef struct { real (*call)(const ClosureEnv*, real); ClosureEnv env; } MatrixInfo;   /* Arc<dyn Fn(f64) -> f64> */
+static real closure_const(const ClosureEnv* e, real t) { (void)t; return e->a; }          /* move |_t| x */
+static real closure_times(const ClosureEnv* e, real t) { return e->a * t; }               /* move |t| x * t */
+static real closure_lerp(const ClosureEnv* e, real t) { return e->a + (e->b - e->a) * t; } /* move |t| s + (x - s) * t */
+typedef struct { MatrixInfo m[16]; Interval valid; } TransformM;   /* column-major like nalgebra: m[col * 4 + row] */
+static void tm_identity(TransformM* tf, real t0, real t1) {
+    for (int i = 0; i < 16; i++) { tf->m[i].call = closure_const; tf->m[i].env.a = (i % 5 == 0) ? R(1.0) : R(0.0); tf->m[i].env.b = R(0.0); }
+    tf->valid.min = t0; tf->valid.max = t1;
+}
+static void tm_set(TransformM* tf, int row, int col, real (*call)(const ClosureEnv*, real), real a, real b) {
+    tf->m[col * 4 + row].call = call; tf->m[col * 4 + row].env.a = a; tf->m[col * 4 + row].env.b = b;
+}
+static void tm_at_time(const TransformM* tf, real t, real out[16]) {   /* Transform::get_matrix_at_time */
+    for (int i = 0; i < 16; i++) {
+        real scaled = r_clamp(iv_proportion(tf->valid, t), R(0.0), R(1.0));
+        out[i] = tf->m[i].call(&tf->m[i].env, scaled);
+    }
+}
+static void mat4_mul(const real a[16], const real b[16], real c[16]) {   /* gemv per column, axpy per term */
+    for (int j = 0; j < 4; j++)
+        for (int i = 0; i < 4; i++) {
+            real y = a[0 * 4 + i] * b[j * 4 + 0];
+            for (int k = 1; k < 4; k++) y = a[k * 4 + i] * b[j * 4 + k] + y;
+            c[j * 4 + i] = y;
+        }
+}
+static void timeline_eval_matrices(const Timeline* tl, real t, int is_sphere, real out[4]) {
+    real tm[16], m[16], tmp[16];
+    for (int i = 0; i < 16; i++) tm[i] = (i % 5 == 0) ? R(1.0) : R(0.0);   /* build_identity_f64 */
+    TransformM tf;
+    tm_identity(&tf, R(-0.1), R(-0.1));                                    /* build_pos(start_pos), always active */
+    for (int r = 0; r < 3; r++) tm_set(&tf, r, 3, closure_const, tl->init[r], R(0.0));
+    tm_at_time(&tf, t, m); mat4_mul(m, tm, tmp); memcpy(tm, tmp, sizeof tm);
+    for (int i = 0; i < tl->n_keys; i++) {
+        const Key* k = &tl->keys[i];
+        if (k->channel > CR_KEY_TZ || !key_active(k, t)) continue;
+        tm_identity(&tf, k->t0, k->t1);
+        tm_set(&tf, k->channel, 3, k->interp == CR_KEY_LERP ? closure_times : closure_const, k->a, R(0.0));
+        tm_at_time(&tf, t, m); mat4_mul(m, tm, tmp); memcpy(tm, tmp, sizeof tm);
+    }
+    /* the last active scale transform: the initial scaler unless a key took over */
+    tm_identity(&tf, R(-0.1), R(-0.1));
+    if (is_sphere) tm_set(&tf, 3, 3, closure_const, tl->init[3], R(0.0));                   /* build_sphere_scaler */
+    else for (int d = 0; d < 4; d++) tm_set(&tf, d, d, closure_const, tl->init[3], R(0.0)); /* build_other_scaler */
+    for (int i = 0; i < tl->n_keys; i++) {
+        const Key* k = &tl->keys[i];
+        if (k->channel <= CR_KEY_TZ || !key_active(k, t)) continue;
+        tm_identity(&tf, k->t0, k->t1);
+        int row = k->channel == CR_KEY_RADIUS ? 3 : (k->channel == CR_KEY_SCALE_X ? 0 : (k->channel == CR_KEY_SCALE_Y ? 1 : 2));
+        int col = k->channel == CR_KEY_RADIUS ? 3 : (k->channel == CR_KEY_SCALE_Y ? 0 : row);   /* ScaleY: row 1, column 0 */
+        tm_set(&tf, row, col, k->interp == CR_KEY_LERP ? closure_lerp : closure_const, k->a, k->b);
+    }
+    real sm[16], comb[16];
+    tm_at_time(&tf, t, sm);
+    mat4_mul(sm, tm, comb);                                                /* scale_matrix * translate_matrix */
+    for (int i = 0; i < 4; i++) {                                          /* combined * (0, 0, 0, 1) */
+        real y = comb[0 * 4 + i] * R(0.0);
+        y = comb[1 * 4 + i] * R(0.0) + y; y = comb[2 * 4 + i] * R(0.0) + y; y = comb[3 * 4 + i] * R(1.0) + y;
+        out[i] = y;
+    }
+}
+
 static void timeline_eval(const Timeline* tl, real t, int is_sphere, real out[4]) {
+    if (g_faithful) { timeline_eval_matrices(tl, t, is_sphere, out); return; }
     real p[3], w;
     int sk;
     timeline_parts(tl, t, 0, p, &w, &sk);
@@ -509,6 +582,7 @@ typedef struct Scene {
     Image* images;
     Key* keys;
     int sky_kind, sky_image;
+    int* mat_rc;             /* faithful mode: stands in for the Arc<Textures> reference counts */
     Hittable* world;         /* BVHWrapper::new_wrapper result */
     Hittable* pool;          /* wrapper nodes */
     int pool_used, pool_cap;
@@ -603,6 +677,26 @@ static int triangle_hit(const Hittable* tr, const Ray* r, Interval ray_t, HitRec
 }
 
 static int hittable_hit(Hittable* h, const Ray* r, Interval ray_t, HitRecord* rec, Counters* cn);
+static int* g_mat_rc = NULL;
+static __thread real g_dead_box[6];
+/* Hittables::update_bb on a leaf child (objects/mod.rs:129-145): recomputes the primitive's box at the ray's time;
+ * BVHWrapper::hit never reads it (bvhwrapper.rs:104-106).  Faithful mode only. */
+static void dead_update_bb(const Hittable* h, real t) {
+    if (h->kind == H_SPHERE) {
+        real sp[4];
+        timeline_eval(&h->tl, t, 1, sp);
+        Aabb b = sphere_bbox(v3(sp[0], sp[1], sp[2]), sp[3]);
+        g_dead_box[0] = b.x.min; g_dead_box[1] = b.x.max; g_dead_box[2] = b.y.min; g_dead_box[3] = b.y.max; g_dead_box[4] = b.z.min; g_dead_box[5] = b.z.max;
+    } else if (h->kind == H_TRIANGLE) {
+        real pa[4], pb[4], pc[4];
+        Timeline tlb = h->tl, tlc = h->tl;
+        tlb.init[0] = h->vb[0]; tlb.init[1] = h->vb[1]; tlb.init[2] = h->vb[2];
+        tlc.init[0] = h->vc[0]; tlc.init[1] = h->vc[1]; tlc.init[2] = h->vc[2];
+        timeline_eval(&h->tl, t, 0, pa); timeline_eval(&tlb, t, 0, pb); timeline_eval(&tlc, t, 0, pc);
+        Aabb b = triangle_bbox(v3(pa[0], pa[1], pa[2]), v3(pb[0], pb[1], pb[2]), v3(pc[0], pc[1], pc[2]));
+        g_dead_box[0] = b.x.min; g_dead_box[1] = b.x.max; g_dead_box[2] = b.y.min; g_dead_box[3] = b.y.max; g_dead_box[4] = b.z.min; g_dead_box[5] = b.z.max;
+    }
+}
 
 /* HitList::hit, hitlist.rs:51-65 */
 static int hitlist_hit(Hittable* l, const Ray* r, Interval ray_t, HitRecord* rec, Counters* cn) {
@@ -620,6 +714,7 @@ static int hitlist_hit(Hittable* l, const Ray* r, Interval ray_t, HitRecord* rec
 static int bvh_hit(Hittable* b, const Ray* r, Interval ray_t, HitRecord* rec, Counters* cn) {
     cn->node_tests++;
     if (!aabb_hit(&b->bbox, r, ray_t)) return 0;
+    if (g_faithful) { dead_update_bb(b->left, r->tm); dead_update_bb(b->right, r->tm); }
     HitRecord hl, hr;
     Hittable *first = b->left, *second = b->right;
     if (b->near_axis) {
@@ -637,12 +732,18 @@ static int bvh_hit(Hittable* b, const Ray* r, Interval ray_t, HitRecord* rec, Co
 }
 
 static int hittable_hit(Hittable* h, const Ray* r, Interval ray_t, HitRecord* rec, Counters* cn) {   /* objects/mod.rs:118-125 */
+    int hit;
     switch (h->kind) {
-        case H_SPHERE: cn->prim_tests++; cn->prim_tests_dedup++; return sphere_hit(h, r, ray_t, rec);
+        case H_SPHERE: cn->prim_tests++; cn->prim_tests_dedup++; hit = sphere_hit(h, r, ray_t, rec); break;
         case H_HITLIST: return hitlist_hit(h, r, ray_t, rec, cn);
         case H_BVH: return bvh_hit(h, r, ray_t, rec, cn);
-        default: cn->prim_tests++; cn->prim_tests_dedup++; return triangle_hit(h, r, ray_t, rec);
+        default: cn->prim_tests++; cn->prim_tests_dedup++; hit = triangle_hit(h, r, ray_t, rec); break;
     }
+    if (hit && g_faithful && g_mat_rc) {   /* HitRecord { mat: mat.clone() } and rec.material() clone the Arc, both dropped later */
+        __sync_fetch_and_add(&g_mat_rc[h->mat], 2);
+        __sync_fetch_and_sub(&g_mat_rc[h->mat], 2);
+    }
+    return hit;
 }
 
 /* ------------------------------------------------------------------ BVH build */
@@ -943,12 +1044,13 @@ EXPORT int32_t oracle_real_type(void) { return ORACLE_REAL_TYPE; }
 EXPORT void oracle_scene_destroy(Scene* sc) {
     if (!sc) return;
     for (int i = 0; i < sc->n_images; i++) free(sc->images[i].rgb);
-    free(sc->images); free(sc->prims); free(sc->materials); free(sc->textures); free(sc->keys); free(sc->pool);
+    free(sc->images); free(sc->prims); free(sc->materials); free(sc->textures); free(sc->keys); free(sc->pool); free(sc->mat_rc);
     free(sc->empty_list.objs);
     free(sc);
 }
 
 EXPORT void oracle_set_libm(int32_t use_glibc) { g_use_libm = use_glibc != 0; }
+EXPORT void oracle_set_faithful(int32_t on) { g_faithful = on != 0; }
 EXPORT void oracle_trig(const real* in, int32_t n, real* atan2_out, real* asin_out, real* acos_out) {   /* in: n pairs (y, x) */
     for (int32_t i = 0; i < n; i++) {
         atan2_out[i] = R_ATAN2(in[2 * i], in[2 * i + 1]);
@@ -971,6 +1073,7 @@ EXPORT Scene* oracle_scene_create(const CrSceneDesc* d) {
         sc->materials[i].albedo = c3((real)m->albedo[0], (real)m->albedo[1], (real)m->albedo[2]);
         sc->materials[i].param = (real)m->param;
     }
+    sc->mat_rc = (int*)calloc((size_t)d->n_materials + 1, sizeof(int));
     sc->textures = (Texture*)malloc(sizeof(Texture) * (size_t)(d->n_textures + 1));
     for (int i = 0; i < d->n_textures; i++) {
         const CrTexture* t = &d->textures[i];
@@ -1095,11 +1198,24 @@ typedef struct {
     Counters cn; uint64_t nan_pixels;
 } Job;
 
+static pthread_mutex_t g_receiver = PTHREAD_MUTEX_INITIALIZER;
 static void* worker(void* arg) {   /* one pixel per work item, cpu_threading.rs:85-101 */
     Job* jb = (Job*)arg;
     const int W = jb->cam->W;
+    void* world_clone = NULL;
+    if (g_faithful) {   /* `let mut world = world.clone()` per thread, cpu_threading.rs:44: a deep copy of every primitive */
+        size_t bytes = sizeof(Hittable) * (size_t)(jb->sc->n_prims + 1) + sizeof(Key) * (size_t)(jb->sc->n_keys + 1);
+        world_clone = malloc(bytes);
+        memcpy(world_clone, jb->sc->prims, sizeof(Hittable) * (size_t)(jb->sc->n_prims + 1));
+        memcpy((char*)world_clone + sizeof(Hittable) * (size_t)(jb->sc->n_prims + 1), jb->sc->keys, sizeof(Key) * (size_t)(jb->sc->n_keys + 1));
+    }
     for (;;) {
-        int64_t pix = __sync_fetch_and_add(jb->next, 1);
+        int64_t pix;
+        if (g_faithful) {   /* receiver.lock().unwrap().recv(), cpu_threading.rs:88 */
+            pthread_mutex_lock(&g_receiver);
+            pix = *jb->next; *jb->next = pix + 1;
+            pthread_mutex_unlock(&g_receiver);
+        } else pix = __sync_fetch_and_add(jb->next, 1);
         if (pix >= jb->pix_end) break;
         uint32_t i = (uint32_t)(pix % W), j = (uint32_t)(pix / W);
         real sum[3];
@@ -1112,6 +1228,7 @@ static void* worker(void* arg) {   /* one pixel per work item, cpu_threading.rs:
             for (int k = 0; k < 3; k++) if (!(o[k] >= R(0.0) && o[k] <= R(1.0))) { jb->nan_pixels++; break; }   /* Color::new asserts */
         }
     }
+    free(world_clone);
     return NULL;
 }
 
@@ -1129,6 +1246,7 @@ EXPORT int32_t oracle_render(const Scene* sc, const CrCameraDesc* cd, const CrRe
         scene_prepare_boxes((Scene*)sc, p->refit_boxes, current_time, current_time + shutter_length);
     }
     volatile int64_t next = pix_begin;
+    g_mat_rc = sc->mat_rc;
     Job* jobs = (Job*)calloc((size_t)n_threads, sizeof(Job));
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
     for (int t = 0; t < n_threads; t++) {

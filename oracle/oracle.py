@@ -78,6 +78,8 @@ class Oracle:
         L.oracle_set_tree.restype = C.c_int32
         L.oracle_use_list.argtypes = [P]
         L.oracle_use_list.restype = None
+        L.oracle_set_faithful.argtypes = [C.c_int32]
+        L.oracle_set_faithful.restype = None
         L.oracle_set_libm.argtypes = [C.c_int32]
         L.oracle_set_libm.restype = None
         L.oracle_trig.argtypes = [P, C.c_int32, P, P, P]
@@ -95,6 +97,11 @@ class Oracle:
         out = np.zeros(n_out, dtype=self.np_real)
         getattr(self.lib, name)(*[self._p(i) for i in ins], self._p(out))
         return out
+
+    def set_faithful(self, on):
+        """Evaluate timelines, update_bb, material clones and the pixel hand-out the way the reference does at every
+        hit (bench.py's `faithful` CPU baseline); results are unchanged, only slower."""
+        self.lib.oracle_set_faithful(1 if on else 0)
 
     # ---- atan2 / asin / acos: the build's defined functions (default) or glibc's (what the Rust binary would call here)
     def set_libm(self, use_glibc):

@@ -368,3 +368,22 @@ def test_images_do_not_depend_on_which_trig_is_used(o64):
     finally:
         o64.set_libm(False)
     assert (a == b).all(axis=2).mean() >= 0.999 and sa["segments"] == sb["segments"] and sa["texel_fetches"] == sb["texel_fetches"]
+
+
+def test_faithful_evaluation_is_the_same_arithmetic(oracles):
+    """bench.py's second CPU baseline (SURVEY 8(d) "faithful"): timelines through 4x4 matrices of closures evaluated
+    at every hit (timeline/mod.rs:90-96,233-263), the dead update_bb calls (bvhwrapper.rs:104-106), material
+    reference counts and the per-pixel mutex.  It must change the time, never a bit of the image."""
+    import scenes
+    from crucible_amd.demo_builder import book1_end_scene
+    for rt, o in oracles.items():
+        for sc in (book1_end_scene(1, scene_seed=2, image_width=96, samples=3), scenes.mixed_scene(48, 3, animate=True),
+                   scenes.scaled_scene(64, 3, frame=1), scenes.moving_scene(64, 3, frame=0)):
+            a, sa = o.render_image(sc, seed=11, n_threads=2)
+            o.set_faithful(True)
+            try:
+                b, sb = o.render_image(sc, seed=11, n_threads=2)
+            finally:
+                o.set_faithful(False)
+            assert np.array_equal(a, b)
+            assert all(sa[k] == sb[k] for k in ("segments", "node_tests", "prim_tests", "texel_fetches"))
