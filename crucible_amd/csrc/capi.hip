@@ -33,18 +33,24 @@ namespace {
 thread_local std::string g_create_error;
 
 struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    hipError_t ensure(size_t n) {
-        if (n <= bytes) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr; bytes = 0;
-        hipError_t e = hipMalloc(&p, n);
-        if (e == hipSuccess) bytes = n;
+    void* p = nullptr;      // what users address: raw + pad
+    void* raw = nullptr;    // the allocation (hipMalloc aligns it to 256 bytes)
+    size_t bytes = 0, pad = 0;
+    // pad: bytes skipped at the front, so that p is deliberately MISaligned by that much (see entry_pad)
+    hipError_t ensure(size_t n, size_t front_pad = 0) {
+        if (n <= bytes && front_pad == pad) return hipSuccess;
+        if (raw) (void)hipFree(raw);
+        p = raw = nullptr; bytes = 0; pad = 0;
+        hipError_t e = hipMalloc(&raw, n + front_pad);
+        if (e == hipSuccess) { bytes = n; pad = front_pad; p = (char*)raw + front_pad; }
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    void release() { if (raw) (void)hipFree(raw); p = raw = nullptr; bytes = 0; pad = 0; }
 };
+// Sibling wrappers are adjacent in the level-order array and start at ODD indices (1,2), (3,4), ...  Skipping one
+// entry at the front of the allocation puts every pair on one 2*sizeof(Entry) boundary: the two children of a
+// wrapper then share a cache line (f64: exactly one 128-byte line), so the walk's left-then-right visits touch it once.
+template <typename E> constexpr size_t entry_pad() { return (sizeof(E) & (sizeof(E) - 1)) == 0 ? sizeof(E) : 0; }
 
 template <typename real> struct DevScene {
     bool built = false;
@@ -605,8 +611,8 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
         keys[i].channel = k.channel; keys[i].interp = k.interp;
     }
 
-    auto up = [&](DevBuf& d, const void* src_p, size_t bytes) -> hipError_t {
-        hipError_t e = d.ensure(bytes ? bytes : 16);
+    auto up = [&](DevBuf& d, const void* src_p, size_t bytes, size_t front_pad = 0) -> hipError_t {
+        hipError_t e = d.ensure(bytes ? bytes : 16, front_pad);
         if (e != hipSuccess) return e;
         if (bytes) return hipMemcpy(d.p, src_p, bytes, hipMemcpyHostToDevice);
         return hipSuccess;
@@ -632,9 +638,9 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
                 eo[farc].skip[o] = eo[i].skip[o];
             }
         }
-        HIP_TRY(h, up(ds.entries, eo.data(), eo.size() * sizeof(EntryO<real>)));
+        HIP_TRY(h, up(ds.entries, eo.data(), eo.size() * sizeof(EntryO<real>), entry_pad<EntryO<real>>()));
     } else
-    HIP_TRY(h, up(ds.entries, b.entries.data(), b.entries.size() * sizeof(Entry<real>)));
+    HIP_TRY(h, up(ds.entries, b.entries.data(), b.entries.size() * sizeof(Entry<real>), entry_pad<Entry<real>>()));
     HIP_TRY(h, up(ds.prims, leaf_prims.data(), leaf_prims.size() * sizeof(Prim<real>)));
     HIP_TRY(h, up(ds.mats, mats.data(), mats.size() * sizeof(Mat<real>)));
     HIP_TRY(h, up(ds.texs, texs.data(), texs.size() * sizeof(Tex<real>)));
@@ -1054,7 +1060,7 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     a.output_sum = p->output_sum;
     if (refit) {   // refit.hpp: wrapper boxes for this frame's ray times [current_time, current_time + shutter_length]
         const size_t bytes = (size_t)ds.n_entries * ds.entry_bytes;
-        HIP_TRY(h, ds.entries_refit.ensure(bytes));
+        HIP_TRY(h, ds.entries_refit.ensure(bytes, ds.entries.pad));
         HIP_TRY(h, hipMemcpyAsync(ds.entries_refit.p, ds.entries.p, bytes, hipMemcpyDeviceToDevice, h->stream));
         { int32_t rc = run_box_kernels<real>(h, ds, ds.entries_refit.p, a.current_time, a.current_time + a.shutter_length, true); if (rc != CR_OK) return rc; }
         a.entries = (const Entry<real>*)ds.entries_refit.p;

@@ -823,9 +823,27 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
             // `it` is the same in every lane still in the loop (a scalar register); tmax cannot change inside it
             const real tmax = w.best_t;
             uint32_t nodes = 0;
+#ifdef CR_X_SIBLING
+            // While a LEFT child read from global memory is tested, its right sibling (the adjacent entry, same cache
+            // line) is already on its way: a left child's skip link IS its sibling, so after a miss or a leaf the walk
+            // continues there without another round trip.
+            Entry<real> nxt;
+            int32_t nxt_idx = -1;
+#endif
             for (uint32_t it = 0; w.idx < n_entries; it++) {
+#ifdef CR_X_SIBLING
+                Entry<real> e;
+                if (RES != RES_LDS && !ORD) {
+                    const int32_t cur = w.idx;
+                    if (cur == nxt_idx) e = nxt;
+                    else e = fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, cur);
+                    if ((cur & 1) && cur >= A.lds_entries && cur + 1 < n_entries) { nxt = A.entries[cur + 1]; nxt_idx = cur + 1; }
+                } else e = ORD ? fetch_entry_ordered<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx, w.oct)
+                               : fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx);
+#else
                 const Entry<real> e = ORD ? fetch_entry_ordered<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx, w.oct)
                                           : fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx);
+#endif
                 nodes++;
                 CR_DIAG_HIT(dg, DG_BOX_WAVE, DG_BOX_LANE);
                 const bool miss = box_miss_fast(e.b, ox, oy, oz, ix, iy, iz, tmin, tmax);

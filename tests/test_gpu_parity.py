@@ -568,3 +568,62 @@ def test_f32_mode_deviation_from_the_reference_arithmetic(renderer):
     assert d.mean() < 1e-2
     ratio = sb["segments"] / sa["segments"]
     assert 1.04 < ratio < 1.15, ratio                 # measured 1.09
+
+
+def _full_size_checks(renderer, oracle, sc, rt, rows, shard_check=True):
+    """The size-independent properties of a full-size frame at 2 spp: every pixel in [0,1], the listed rows bit-for-bit
+    against the oracle, two runs identical (image and counters), two 1-sample shards add up to the 2-sample frame."""
+    cam = sc.scene_cam
+    W, H = cam.image_width, cam.image_height
+    flat = sc.flatten()
+    renderer.upload_scene(flat)
+    img, st = renderer.render(cam, seed=SEED, real_type=rt)
+    assert st["samples"] == W * H * cam.samples and st["nan_pixels"] == 0
+    assert img.min() >= 0.0 and img.max() <= 1.0
+    again, st2 = renderer.render(cam, seed=SEED, real_type=rt)
+    assert np.array_equal(img, again) and all(st[k] == st2[k] for k in COUNTERS)
+    h = oracle.scene_create(flat)
+    try:
+        for row in rows:
+            ref, _ = oracle.render(h, cam, seed=SEED, pix_begin=row * W, pix_end=(row + 1) * W)
+            assert np.array_equal(img[row], ref), row
+    finally:
+        oracle.scene_destroy(h)
+    if shard_check:
+        s0, _ = renderer.render(cam, seed=SEED, real_type=rt, sample_begin=0, sample_count=1, output_sum=True)
+        s1, _ = renderer.render(cam, seed=SEED, real_type=rt, sample_begin=1, sample_count=1, output_sum=True)
+        assert np.array_equal((s0 + s1) / img.dtype.type(2), img)
+    return img, st
+
+
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+def test_full_size_teapot_with_the_full_environment_map(renderer, oracles, rt, tag):
+    """BASELINE config 3's frame: teapot (6320 triangles) + ground at 1920x1080 under the 2048x1024 spherical map."""
+    sc = load_teapot(1, image_width=1920, samples=2, sky=procedural_sky())
+    assert sc.flatten().images[0].width == 2048 and sc.flatten().images[0].height == 1024
+    img, st = _full_size_checks(renderer, oracles[rt], sc, rt, rows=(3, 402, 640, 1077))
+    assert st["bvh_entries"] == 8191 and st["texel_fetches"] > 0.3 * st["samples"]
+
+
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+def test_full_size_million_spheres_at_4k(renderer, oracles, rt, tag):
+    """BASELINE config 4's frame: 1 000 001 spheres at 3840x2160 (2 spp): the 1 048 575-wrapper tree walked from
+    every pixel of the real frame; four rows against the oracle's recursive tree."""
+    sc = million_spheres(1, scene_seed=1, half_extent=500, image_width=3840, samples=2)
+    assert (sc.scene_cam.image_width, sc.scene_cam.image_height) == (3840, 2160)
+    img, st = _full_size_checks(renderer, oracles[rt], sc, rt, rows=(0, 701, 1350, 2159))
+    assert st["bvh_entries"] == 1048575
+
+
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+def test_full_size_movie_frame(renderer, oracles, rt, tag):
+    """One frame of BASELINE config 5 (the teapot orbit at 1920x1080, frame 37 of 240): camera keyframes evaluated per
+    sample, spherical map."""
+    from crucible_amd.demo_builder import teapot_orbit_movie
+    sc = teapot_orbit_movie(1, image_width=1920, samples=2)
+    sc.scene_cam.frame = 37
+    img, _ = _full_size_checks(renderer, oracles[rt], sc, rt, rows=(11, 540, 1000))
+    sc.scene_cam.frame = 38
+    renderer.upload_scene(sc.flatten())
+    nxt, _ = renderer.render(sc.scene_cam, seed=SEED, real_type=rt)
+    assert not np.array_equal(img, nxt)       # the camera moved between frames
