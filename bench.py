@@ -141,6 +141,9 @@ def main():
     ap.add_argument("--bvh", choices=["reference", "sah", "ordered", "lbvh"], default="reference",
                     help="reference = the reference's median-split tree (parity mode, the headline); the others are the opt-in "
                          "trees of SURVEY 8(f) row 1 (extra lines, not the headline)")
+    ap.add_argument("--force-group", action="store_true",
+                    help="diagnostic: go through cr_group_render even with one GPU (with CRUCIBLE_GROUP_FORCE_RCCL=1 the one-rank RCCL "
+                         "communicator and its reduce are exercised too)")
     ap.add_argument("--reduce", choices=["library", "torch", "gloo"], default="library",
                     help="N>1: library = cr_group_render (RCCL reduce inside the C ABI); torch = torch.distributed (nccl) reduce of the "
                          "sums; gloo = reduce host copies (rehearsal of the multi-rank flow with ranks sharing one GPU)")
@@ -203,22 +206,29 @@ def main():
 
     # ---- the renderer: one handle, or (N > 1, spp split) a library group whose reduce is RCCL inside the C ABI
     group, group_error, reduce_how, torch_pg = None, None, None, None
-    if spp_split and args.reduce == "library":
+    if (spp_split and args.reduce == "library") or (args.force_group and world == 1 and not frame_sharded):
         try:
-            ident = torch.zeros(A.CR_GROUP_ID_BYTES, dtype=torch.uint8, device=ctl)
-            if rank == 0:
-                ident = torch.tensor(list(RenderGroup.unique_id()), dtype=torch.uint8, device=ctl)
-            dist.broadcast(ident, src=0)
-            group = RenderGroup.rank(dev_index, rank, world, bytes(ident.cpu().tolist()))
+            ident = None
+            if world > 1 or os.environ.get("CRUCIBLE_GROUP_FORCE_RCCL"):
+                ident = torch.zeros(A.CR_GROUP_ID_BYTES, dtype=torch.uint8, device=ctl)
+                if rank == 0:
+                    ident = torch.tensor(list(RenderGroup.unique_id()), dtype=torch.uint8, device=ctl)
+                if world > 1:
+                    dist.broadcast(ident, src=0)
+                ident = bytes(ident.cpu().tolist())
+            group = RenderGroup.rank(dev_index, rank, world, ident)
             group.upload_scene(flat)
         except (CrucibleError, OSError) as e:
             group, group_error = None, str(e)
-        ok = torch.tensor([1 if group is not None else 0], dtype=torch.int32, device=ctl)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:          # any rank without RCCL inside the library: everybody falls back together
-            if group is not None:
-                group.close()
-            group = None
+        if world > 1:
+            ok = torch.tensor([1 if group is not None else 0], dtype=torch.int32, device=ctl)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:          # any rank without RCCL inside the library: everybody falls back together
+                if group is not None:
+                    group.close()
+                group = None
+        elif group is None:
+            raise SystemExit(f"--force-group: {group_error}")
     if spp_split and group is None and args.reduce == "gloo":
         reduce_how = "gloo reduce of host copies of the per-pixel sums (rehearsal)"
     elif spp_split and group is None:
@@ -335,7 +345,7 @@ def main():
                                "ordered": "binned SAH topology walked near child first (CR_BVH_SAH_ORDERED; not the reference's tree or order)",
                                "lbvh": "Morton-code LBVH built on the device (CR_BVH_LBVH; not the reference's tree)"}[args.bvh],
                        "scene_residency": {0: "L2", 1: "whole scene in LDS", 2: "BVH top levels in LDS"}.get(st["scene_in_lds"]),
-                       "parallelism": "1 GPU" if world == 1 else (f"frame-shard x{world}, no collective" if frame_sharded else
+                       "parallelism": ("1 GPU" + (" through cr_group_render" if group is not None else "")) if world == 1 else (f"frame-shard x{world}, no collective" if frame_sharded else
                                                                      f"spp-shard x{world}: {reduce_how}")},
             "roofline": {"bound": "valu", "achieved": round(tflops, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
                          "traffic": traffic,

@@ -821,7 +821,11 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
             const Pair<real> ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
             const Pair<real> ix = {w.inv.x, w.inv.x}, iy = {w.inv.y, w.inv.y}, iz = {w.inv.z, w.inv.z};
             // `it` is the same in every lane still in the loop (a scalar register); tmax cannot change inside it
+#ifdef CR_X_CANON
+            const real tmax = __builtin_canonicalize(w.best_t);   // once, not per step: v_min(x, tmax) needs a quieted tmax
+#else
             const real tmax = w.best_t;
+#endif
             uint32_t nodes = 0;
 #ifdef CR_X_SIBLING
             // While a LEFT child read from global memory is tested, its right sibling (the adjacent entry, same cache
@@ -1123,9 +1127,13 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
 // LDS window: there the walk waits on L2 / HBM reads and more resident waves hide more of that latency than the
 // extra spills cost (1M spheres +11 %; the LDS-resident book1 and the 8K-wrapper teapot lose 3 % and stay on
 // pathtrace_kernel).  RES_TOP only.
-constexpr int LatencyBlock = 512;
+#ifndef CR_LAT_BLOCK
+#define CR_LAT_BLOCK 512
+#define CR_LAT_WAVES 6
+#endif
+constexpr int LatencyBlock = CR_LAT_BLOCK;
 template <typename real, bool ANIM, bool ORD = false>
-__global__ void __attribute__((amdgpu_flat_work_group_size(64, LatencyBlock), amdgpu_waves_per_eu(6, 6)))
+__global__ void __attribute__((amdgpu_flat_work_group_size(64, LatencyBlock), amdgpu_waves_per_eu(CR_LAT_WAVES, CR_LAT_WAVES)))
 pathtrace_kernel_latency(const KernelArgs<real> A) {
     pathtrace_body<real, RES_TOP, ANIM, ORD>(A);
 }
