@@ -683,9 +683,8 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
     // Workgroup size: the candidate that keeps the most waves resident per CU (a larger
     // workgroup shares one LDS copy of the scene among more waves); ties go to the larger.
     int block = 256, per_cu = 1, best_waves = 0;
-    for (int cand : {1024, 512, 320, 256}) {
+    for (int cand : {1024, 512, 256}) {
         if (cand > max_block) continue;
-        if (cand == 320 && !LATENCY) continue;
         if (h->block_override > 0 && cand != h->block_override && h->block_override <= max_block) continue;
         int n = 0;
         HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, cand, LDS ? lds_bytes : 0));
@@ -1112,18 +1111,11 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
         return anim ? launch<real, RES_LDS, true>(h, a, ds.lds_bytes, stats) : launch<real, RES_LDS, false>(h, a, ds.lds_bytes, stats);
     }
     constexpr bool f32 = std::is_same<real, float>::value;   // the double kernel needs far more than 80 VGPRs: it halves there
-#ifdef CR_X_LAT_F64
-    const bool latency = h->latency_entries > 0 && ds.n_entries > h->latency_entries;
-#else
     const bool latency = f32 && h->latency_entries > 0 && ds.n_entries > h->latency_entries;
-#endif
     const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, (latency ? h->latency_top_bytes : h->lds_top_bytes) / sizeof(Entry<real>));
     if (top > 0) {   // large scene: the top levels of the tree in LDS, everything else through L2
         a.lds_entries = top;
         const size_t bytes = (size_t)top * sizeof(Entry<real>);
-#ifdef CR_X_LAT_F64
-        if (latency) return anim ? launch<real, RES_TOP, true, false, true>(h, a, bytes, stats) : launch<real, RES_TOP, false, false, true>(h, a, bytes, stats);
-#endif
         if constexpr (f32) if (latency) return anim ? launch<real, RES_TOP, true, false, true>(h, a, bytes, stats) : launch<real, RES_TOP, false, false, true>(h, a, bytes, stats);
         return anim ? launch<real, RES_TOP, true>(h, a, bytes, stats) : launch<real, RES_TOP, false>(h, a, bytes, stats);
     }

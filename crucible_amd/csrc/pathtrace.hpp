@@ -565,6 +565,62 @@ template <typename real> CR_D real r_atan2(real y, real x) { return soft_atan2(y
 template <typename real> CR_D real r_asin(real x) { return soft_asin(x); }
 template <typename real> CR_D real r_acos(real x) { return soft_acos(x); }
 
+// random_unit_vector (utils.rs:127-136) and random_in_unit_disk (utils.rs:110-124) for the f64 kernel, with the
+// rejection test SCREENED in f32.  A wave leaves a rejection loop only when its slowest lane does (six rounds for a
+// unit vector with ~36 lanes drawing), and in f64 most of a round is converting three 64-bit draws to doubles just to
+// throw half of them away.  The screen uses the top 24 bits of each draw: xf = -1 + 2*(u >> 40)*2^-24 is EXACT in f32
+// and within 2^-23 of the f64 coordinate, so the f32 squared length lf differs from the f64 one by less than 2e-6
+// (3 * 2 * 2^-23 from the truncation, < 1e-6 from f32 rounding).  Hence
+//     lf > 1 + 1e-5              =>  the reference's test `lensq <= 1` fails      -> next round, nothing converted
+//     1e-5 < lf < 1 - 1e-5       =>  it passes (1e-160 < lensq <= 1)             -> leave the loop with the raw draws
+// and only a candidate inside the 2e-5 band (or with lf <= 1e-5) is decided by evaluating the reference's f64
+// expression on the spot -- a branch no lane takes in ~99.9 % of the rounds.  The accepted candidate is converted to
+// f64 once, after the loop, with the reference's expression tree; draws consumed and results are those of the plain
+// loop, bit for bit (the parity tests run every f64 scene through this).
+CR_D float screen_coord(uint64_t u) {   // -1 + 2 * u01(u, float): (top24 - 2^23) * 2^-23, exact
+    return (float)((int32_t)(uint32_t)(u >> 40) - (int32_t)(1 << 23)) * 0x1.0p-23f;
+}
+template <typename real> CR_D V3<real> random_unit_vector_dev(uint64_t& s) {
+    if constexpr (!std::is_same<real, double>::value) return random_unit_vector<real>(s);
+    else {
+        uint64_t ux, uy, uz;
+        for (;;) {
+            ux = rng_next(s); uy = rng_next(s); uz = rng_next(s);
+            const float fx = screen_coord(ux), fy = screen_coord(uy), fz = screen_coord(uz);
+            const float lf = fx * fx + fy * fy + fz * fz;
+            if (lf > 1.0f + 1e-5f) continue;
+            if (lf > 1e-5f && lf < 1.0f - 1e-5f) break;
+            const double x = -1.0 + 2.0 * u01(ux, 0.0), y = -1.0 + 2.0 * u01(uy, 0.0), z = -1.0 + 2.0 * u01(uz, 0.0);
+            const double lensq = x * x + y * y + z * z;
+            if (RealTraits<double>::tiny < lensq && lensq <= 1.0) break;
+        }
+        // rng_range(-1, 1) = lo + (hi - lo) * u with hi - lo = 2 exactly
+        const V3<double> p = mk<double>(-1.0 + 2.0 * u01(ux, 0.0), -1.0 + 2.0 * u01(uy, 0.0), -1.0 + 2.0 * u01(uz, 0.0));
+        return divs(p, r_sqrt(len2(p)));
+    }
+}
+template <typename real> CR_D void random_in_unit_disk_dev(uint64_t& s, real& px, real& py) {
+    if constexpr (!std::is_same<real, double>::value) {
+        for (;;) {
+            px = rng_range<real>(s, real(-1), real(1));
+            py = rng_range<real>(s, real(-1), real(1));
+            if (px * px + py * py + real(0) * real(0) < real(1)) break;
+        }
+    } else {
+        uint64_t ux, uy;
+        for (;;) {
+            ux = rng_next(s); uy = rng_next(s);
+            const float fx = screen_coord(ux), fy = screen_coord(uy);
+            const float lf = fx * fx + fy * fy;
+            if (lf > 1.0f + 1e-5f) continue;
+            if (lf < 1.0f - 1e-5f) break;
+            const double x = -1.0 + 2.0 * u01(ux, 0.0), y = -1.0 + 2.0 * u01(uy, 0.0);
+            if (x * x + y * y + 0.0 * 0.0 < 1.0) break;
+        }
+        px = -1.0 + 2.0 * u01(ux, 0.0); py = -1.0 + 2.0 * u01(uy, 0.0);
+    }
+}
+
 // Camera::cast_ray's per-sample ray (ray_casting.rs:82-105): seeds the sample's RNG stream and draws
 // time, pixel offset and (with defocus) the lens point, in the reference's order.
 template <typename real, bool ANIM>
@@ -590,11 +646,7 @@ CR_D void camera_ray(const KernelArgs<real>& A, uint32_t pix_i, uint32_t pix_j, 
     V3<real> orig = f.from;
     if (cam.defocus_on) {   // defocus_disk_sample :104-110, random_in_unit_disk utils.rs:110-124
         real px, py;
-        for (;;) {
-            px = rng_range<real>(rng, real(-1), real(1));
-            py = rng_range<real>(rng, real(-1), real(1));
-            if (px * px + py * py + real(0) * real(0) < real(1)) break;
-        }
+        random_in_unit_disk_dev<real>(rng, px, py);
         orig = add(add(f.from, scale(px, f.ddu)), scale(py, f.ddv));
     }
     ro = orig; rd = sub(ps, orig); rtime = ts;
@@ -672,7 +724,7 @@ CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<re
         }
         CR_DIAG_LANE(dg, m.kind == 0 ? DG_LAMB_LANE : (m.kind == 1 ? DG_METAL_LANE : DG_DIEL_LANE));
 #else
-        if (m.kind != 2) ruv = random_unit_vector<real>(rng);
+        if (m.kind != 2) ruv = random_unit_vector_dev<real>(rng);
 #endif
         if (m.kind == 0) {                                  // lambertian.rs:40-61
             V3<real> dir = add(n, ruv);
@@ -821,33 +873,11 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
             const Pair<real> ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
             const Pair<real> ix = {w.inv.x, w.inv.x}, iy = {w.inv.y, w.inv.y}, iz = {w.inv.z, w.inv.z};
             // `it` is the same in every lane still in the loop (a scalar register); tmax cannot change inside it
-#ifdef CR_X_CANON
-            const real tmax = __builtin_canonicalize(w.best_t);   // once, not per step: v_min(x, tmax) needs a quieted tmax
-#else
             const real tmax = w.best_t;
-#endif
             uint32_t nodes = 0;
-#ifdef CR_X_SIBLING
-            // While a LEFT child read from global memory is tested, its right sibling (the adjacent entry, same cache
-            // line) is already on its way: a left child's skip link IS its sibling, so after a miss or a leaf the walk
-            // continues there without another round trip.
-            Entry<real> nxt;
-            int32_t nxt_idx = -1;
-#endif
             for (uint32_t it = 0; w.idx < n_entries; it++) {
-#ifdef CR_X_SIBLING
-                Entry<real> e;
-                if (RES != RES_LDS && !ORD) {
-                    const int32_t cur = w.idx;
-                    if (cur == nxt_idx) e = nxt;
-                    else e = fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, cur);
-                    if ((cur & 1) && cur >= A.lds_entries && cur + 1 < n_entries) { nxt = A.entries[cur + 1]; nxt_idx = cur + 1; }
-                } else e = ORD ? fetch_entry_ordered<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx, w.oct)
-                               : fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx);
-#else
                 const Entry<real> e = ORD ? fetch_entry_ordered<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx, w.oct)
                                           : fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx);
-#endif
                 nodes++;
                 CR_DIAG_HIT(dg, DG_BOX_WAVE, DG_BOX_LANE);
                 const bool miss = box_miss_fast(e.b, ox, oy, oz, ix, iy, iz, tmin, tmax);
@@ -1127,13 +1157,9 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
 // LDS window: there the walk waits on L2 / HBM reads and more resident waves hide more of that latency than the
 // extra spills cost (1M spheres +11 %; the LDS-resident book1 and the 8K-wrapper teapot lose 3 % and stay on
 // pathtrace_kernel).  RES_TOP only.
-#ifndef CR_LAT_BLOCK
-#define CR_LAT_BLOCK 512
-#define CR_LAT_WAVES 6
-#endif
-constexpr int LatencyBlock = CR_LAT_BLOCK;
+constexpr int LatencyBlock = 512;
 template <typename real, bool ANIM, bool ORD = false>
-__global__ void __attribute__((amdgpu_flat_work_group_size(64, LatencyBlock), amdgpu_waves_per_eu(CR_LAT_WAVES, CR_LAT_WAVES)))
+__global__ void __attribute__((amdgpu_flat_work_group_size(64, LatencyBlock), amdgpu_waves_per_eu(6, 6)))
 pathtrace_kernel_latency(const KernelArgs<real> A) {
     pathtrace_body<real, RES_TOP, ANIM, ORD>(A);
 }
