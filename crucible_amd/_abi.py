@@ -108,6 +108,8 @@ SYMBOLS = {
     "cr_group_upload_scene": (C.c_int32, [C.c_void_p, C.POINTER(CrSceneDesc)]),
     "cr_group_render": (C.c_int32, [C.c_void_p, C.POINTER(CrCameraDesc), C.POINTER(CrRenderParams), C.c_void_p,
                                     C.POINTER(CrGroupStats)]),
+    "cr_group_render_host": (C.c_int32, [C.c_void_p, C.POINTER(CrCameraDesc), C.POINTER(CrRenderParams), C.c_void_p,
+                                         C.POINTER(CrGroupStats)]),
     "cr_group_last_error": (C.c_char_p, [C.c_void_p]),
 }
 

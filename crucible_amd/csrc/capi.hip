@@ -1706,4 +1706,39 @@ int32_t cr_group_render(CrGroup* g, const CrCameraDesc* cam, const CrRenderParam
     return CR_OK;
 }
 
+int32_t cr_group_render_host(CrGroup* g, const CrCameraDesc* cam, const CrRenderParams* params, void* h_out, CrGroupStats* stats) {
+    if (!g) return CR_ERR_INVALID_ARG;
+    if (!cam || !params) return gfail(g, CR_ERR_INVALID_ARG, "null camera or params");
+    const bool root_here = g->first == 0;
+    if (root_here && !h_out) return gfail(g, CR_ERR_INVALID_ARG, "the root member needs an output buffer");
+    if (cam->image_width < 1 || cam->image_height < 1) return gfail(g, CR_ERR_INVALID_ARG, "image size must be positive");
+    CrHandle* root = g->members[0];
+    const size_t n = (size_t)cam->image_width * (size_t)cam->image_height * 3;
+    const size_t bytes = n * real_size(params->real_type);
+    void* d_out = nullptr;
+    if (root_here) {
+        GHIP_TRY(g, hipSetDevice(root->device));
+        GHIP_TRY(g, root->out_buf.ensure(bytes));
+        d_out = root->out_buf.p;
+    }
+    CrGroupStats local;
+    int32_t rc = cr_group_render(g, cam, params, d_out, stats ? stats : &local);
+    if (rc != CR_OK || !root_here) return rc;
+    GHIP_TRY(g, hipSetDevice(root->device));
+    GHIP_TRY(g, hipMemcpyAsync(h_out, d_out, bytes, hipMemcpyDeviceToHost, root->stream));
+    GHIP_TRY(g, hipStreamSynchronize(root->stream));
+    uint64_t bad = 0;   // Color::new asserts 0 <= c <= 1 on every mean (ray_casting.rs:172)
+    for (size_t i = 0; i < n / 3; i++) {
+        bool ok = true;
+        for (int k = 0; k < 3; k++) {
+            const double v = params->real_type == CR_REAL_F64 ? ((const double*)h_out)[3 * i + k] : (double)((const float*)h_out)[3 * i + k];
+            ok = ok && (v >= 0.0 && v <= 1.0);
+        }
+        bad += ok ? 0 : 1;
+    }
+    if (stats) stats->render.nan_pixels = bad;
+    if (bad) return gfail(g, CR_ERR_NAN, "a pixel mean is NaN or outside [0,1] (the reference panics in Color::new)");
+    return CR_OK;
+}
+
 }   // extern "C"

@@ -378,6 +378,8 @@ public:
     bool refit_boxes = false;          // CrRenderParams.refit_boxes: wrapper boxes follow keyframed primitives
     std::string frame_format = "ppm";  // "ppm" (ASCII P3, the reference's) | "p6" | "png"
     int device = 0;
+    int gpus = 1;            // > 1 (or use_group): still images split their samples over devices 0..gpus-1 through cr_group_*;
+    bool use_group = false;  // movies give frame f to device f % gpus (scene/mod.rs:307-316: frames are independent)
 
     Scene(double aspect, uint32_t width, size_t rate, double shutter, size_t threads)
         : scene_cam(aspect, width, (double)rate, shutter, threads), frame_rate(rate) {}
@@ -522,7 +524,70 @@ public:
         int32_t rc = render_frame(h, buf, stats);
         return rc == CR_OK ? write_frame(fname, buf) : rc;
     }
+    // Camera::render across several devices: cr_group_render_host splits the sample indices, adds the per-pixel sums with
+    // one RCCL reduce inside the library and hands back the mean.
+    int32_t render_frame_group(CrGroup* g, std::vector<double>& buf, CrStats* stats = nullptr) const {
+        const Camera& c = scene_cam;
+        std::vector<CrKeyframe> fk = c.look_from_tl.keyframes(), ak = c.look_at_tl.keyframes();
+        CrCameraDesc cd{c.image_width, c.image_height, c.vfov_degrees, c.defocus_angle_degrees, c.focus_dist,
+                        {c.look_from_tl.start_pos.x, c.look_from_tl.start_pos.y, c.look_from_tl.start_pos.z},
+                        {c.look_at_tl.start_pos.x, c.look_at_tl.start_pos.y, c.look_at_tl.start_pos.z},
+                        {c.vup.x, c.vup.y, c.vup.z}, (int32_t)fk.size(), (int32_t)ak.size(), fk.data(), ak.data()};
+        CrRenderParams p{(int32_t)c.samples, 0, (int32_t)c.samples, (int32_t)c.max_depth, seed, (int32_t)c.frame, real_type,
+                         c.frame_rate, c.shutter_angle, 0, refit_boxes ? 1 : 0};
+        buf.resize((size_t)c.image_width * c.image_height * 3);
+        CrGroupStats gs;
+        int32_t rc = cr_group_render_host(g, &cd, &p, buf.data(), &gs);
+        if (stats) *stats = gs.render;
+        return rc;
+    }
+    // One frame of a movie on one member of the group (its own handle, its own host thread).
+    int32_t render_movie_frame(CrHandle* h, size_t frame, const std::string& stem, std::vector<double>& buf) const {
+        Scene copy = *this;                       // the camera's frame counter is per render
+        copy.scene_cam.frame = (uint32_t)frame;
+        int32_t rc = copy.render_frame(h, buf, nullptr);
+        return rc == CR_OK ? copy.write_frame(stem, buf) : rc;
+    }
+    int32_t render_scene_group(const std::string& fname, CrStats* stats) {
+        std::vector<int32_t> ids;
+        for (int i = 0; i < std::max(1, gpus); i++) ids.push_back(device + i);
+        CrGroup* g = nullptr;
+        int32_t rc = cr_group_create(ids.data(), (int32_t)ids.size(), &g);
+        if (rc != CR_OK) { fprintf(stderr, "Render failed. %s\n", cr_group_last_error(nullptr)); return rc; }
+        FlatScene f = flatten();
+        rc = cr_group_upload_scene(g, &f.desc);
+        if (rc == CR_OK && !is_movie) {
+            std::vector<double> buf;
+            rc = render_frame_group(g, buf, stats);
+            if (rc == CR_OK) rc = write_frame(fname, buf);
+        } else if (rc == CR_OK) {   // frames sharded round-robin, one host thread per device, no collective
+            if (mkdir(fname.c_str(), 0777) != 0 || mkdir((fname + "/artifacts").c_str(), 0777) != 0) rc = CR_ERR_IO;
+            const size_t frames = compute_frame_count(), digits = std::to_string(frames).size(), n = ids.size();
+            std::vector<int32_t> member_rc(n, CR_OK);
+            std::vector<std::thread> workers;
+            for (size_t m = 0; rc == CR_OK && m < n; m++)
+                workers.emplace_back([this, g, m, n, frames, digits, &fname, &member_rc] {
+                    std::vector<double> buf;
+                    for (size_t fr = m; fr < frames && member_rc[m] == CR_OK; fr += n) {
+                        std::string num = std::to_string(fr);
+                        num = std::string(digits - num.size(), '0') + num;
+                        member_rc[m] = render_movie_frame(cr_group_handle(g, (int32_t)m), fr, fname + "/artifacts/image" + num, buf);
+                    }
+                });
+            for (std::thread& t : workers) t.join();
+            for (int32_t r : member_rc) if (rc == CR_OK) rc = r;
+            if (rc == CR_OK) {
+                std::string cmd;
+                for (const std::string& a : mp4_command(fname, digits)) cmd += (cmd.empty() ? "" : " ") + (a.find_first_of("*()") != std::string::npos ? "'" + a + "'" : a);
+                fprintf(stderr, "Frames written. To assemble the movie: %s\n", cmd.c_str());
+            }
+        }
+        if (rc != CR_OK) fprintf(stderr, "Render failed. %s\n", cr_group_last_error(g));
+        cr_group_destroy(g);
+        return rc;
+    }
     int32_t render_scene(const std::string& fname, CrStats* stats = nullptr) {
+        if (gpus > 1 || use_group) return render_scene_group(fname, stats);
         CrHandle* h = nullptr;
         int32_t rc = cr_create(device, &h);
         if (rc != CR_OK) { fprintf(stderr, "Render failed. %s\n", cr_last_error(nullptr)); return rc; }

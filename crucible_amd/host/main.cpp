@@ -41,7 +41,8 @@ int main(int argc, char** argv) {
     uint64_t seed = 0xC0FFEE, scene_seed = 1;
     int device = 0;
     std::string bvh = "reference", sky, format = "ppm";
-    bool refit = false;
+    bool refit = false, use_group = false;
+    int gpus = 1;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char* { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
@@ -61,6 +62,8 @@ int main(int argc, char** argv) {
         else if (a == "--sky") sky = next();
         else if (a == "--format") format = next();
         else if (a == "--refit") refit = true;
+        else if (a == "--gpus") gpus = (int)strtol(next(), nullptr, 10);
+        else if (a == "--group") use_group = true;
         else if (a == "--dump-desc") dump = next();
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
@@ -100,6 +103,7 @@ int main(int argc, char** argv) {
         if (bvh != "reference" && bvh != "sah" && bvh != "ordered" && bvh != "lbvh") { fprintf(stderr, "--bvh takes reference, sah, ordered or lbvh\n"); return 2; }
         scene.bvh_mode = bvh == "sah" ? CR_BVH_SAH : (bvh == "ordered" ? CR_BVH_SAH_ORDERED : (bvh == "lbvh" ? CR_BVH_LBVH : CR_BVH_REFERENCE));
         scene.refit_boxes = refit;
+        scene.gpus = std::max(1, gpus); scene.use_group = use_group;
         if (format != "ppm" && format != "p6" && format != "png") { fprintf(stderr, "--format takes ppm, p6 or png\n"); return 2; }
         scene.frame_format = format;
         if (!dump.empty()) { dump_desc(scene.flatten(), dump.c_str()); return 0; }

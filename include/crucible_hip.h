@@ -391,6 +391,10 @@ typedef struct CrGroupStats {
 } CrGroupStats;
 CR_API int32_t cr_group_render(CrGroup* g, const CrCameraDesc* cam, const CrRenderParams* params, void* d_out_rgb,
                                CrGroupStats* stats);
+/* Same, into a HOST buffer on the root (cr_render_host's counterpart: render + reduce + device->host copy, and the
+ * Color::new check of every mean -> CR_ERR_NAN).  Ranks other than the root may pass NULL. */
+CR_API int32_t cr_group_render_host(CrGroup* g, const CrCameraDesc* cam, const CrRenderParams* params, void* h_out_rgb,
+                                    CrGroupStats* stats);
 CR_API const char* cr_group_last_error(CrGroup* g);
 
 #ifdef __cplusplus

@@ -150,3 +150,27 @@ def test_cli_movie_frame_formats_hold_the_same_pixels(cli, tmp_path):
                 out.append(rows[:, 1:].tobytes())
         pix[fmt] = out
     assert pix["ppm"] == pix["p6"] == pix["png"] and len(set(pix["ppm"])) == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_rccl", [False, True], ids=["direct", "rccl"])
+def test_cli_group_path_renders_the_same_files(cli, tmp_path, monkeypatch, force_rccl):
+    """--gpus N / --group: the compiled host drives cr_group_create + cr_group_render_host for a still (samples split
+    over the devices, one RCCL reduce inside the library) and one host thread per device for a movie (frame f on device
+    f % N).  With the one device of this box the files must equal the single-handle path's byte for byte."""
+    if force_rccl:
+        monkeypatch.setenv("CRUCIBLE_GROUP_FORCE_RCCL", "1")
+    a, b = str(tmp_path / "plain"), str(tmp_path / "group")
+    common = ["--world", "1", "--width", "64", "--samples", "3", "--real", "f64"]
+    subprocess.check_call([cli, "--file", a] + common, cwd=ROOT)
+    subprocess.check_call([cli, "--file", b, "--gpus", "1", "--group"] + common, cwd=ROOT)
+    assert open(a + ".ppm").read() == open(b + ".ppm").read()
+    ma, mb = str(tmp_path / "mplain"), str(tmp_path / "mgroup")
+    movie = ["--world", "1", "--movie", "--seconds", "0.75", "--rate", "4", "--width", "32", "--samples", "2"]
+    subprocess.check_call([cli, "--file", ma] + movie, cwd=ROOT)
+    r = subprocess.run([cli, "--file", mb, "--group"] + movie, cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0 and "ffmpeg -framerate 4" in r.stderr
+    names = sorted(os.listdir(os.path.join(ma, "artifacts")))
+    assert names == sorted(os.listdir(os.path.join(mb, "artifacts"))) == ["image0.ppm", "image1.ppm", "image2.ppm"]
+    for n in names:
+        assert open(os.path.join(ma, "artifacts", n)).read() == open(os.path.join(mb, "artifacts", n)).read(), n

@@ -47,6 +47,8 @@ def test_one_member_group_equals_render_device(renderer, oracles, monkeypatch, r
         assert st["samples"] == 96 * 54 * 5 and st["kernel_ms"] > 0
         again, _ = group_image(g, sc, rt)
         assert np.array_equal(again, img)
+        host, hst = g.render(sc.scene_cam, seed=SEED, real_type=rt)        # cr_group_render_host
+        assert np.array_equal(host, img) and hst["nan_pixels"] == 0
     finally:
         g.close()
 
