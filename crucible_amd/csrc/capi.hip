@@ -58,6 +58,7 @@ template <typename real> struct DevScene {
     int32_t n_entries = 0, n_prims = 0, n_mats = 0, n_texs = 0, n_scene_keys = 0;
     size_t lds_bytes = 0;
     bool animated = false;
+    bool has_triangles = false;
     DevBuf entries_refit;                    // working copy whose boxes refit_level_kernel rewrites per frame
     bool ordered = false;                    // CR_BVH_SAH_ORDERED: `entries` holds EntryO records
     size_t entry_bytes = sizeof(Entry<real>);
@@ -120,11 +121,16 @@ struct CrHandle {
     // latency_top_bytes LDS window, three 512-thread groups per CU.  CRUCIBLE_LATENCY_ENTRIES (0 = never).
     int32_t latency_entries = 65536;
     size_t latency_top_bytes = 48 * 1024;
+    size_t lds_side_limit = 16 * 1024;   // RES_TOP: materials + textures join the LDS window up to this size (CRUCIBLE_LDS_SIDE_KB; 0 = never)
     size_t lds_top_bytes = 64 * 1024;   // LDS spent on the top of a tree that does not fit whole (CRUCIBLE_LDS_TOP_KB; 0 = none)
     int blocks_per_cu_override = 0;
     int block_override = 0;
-    int walk_round_steps = 10;         // 0 = a round lasts until every walking lane found a leaf or ran out (measured: 10)
-    int walk_exit_lanes = 56;          // leave the walk phase once this many lanes are not walking (64 = wait for all; measured: 56)
+    // Wave scheduling of the walk (speed only).  -1 = chosen per scene: sphere scenes 10 / 56, scenes with triangles 8 / 40 --
+    // a triangle test is ~1.5x a sphere test, so parked lanes are dearer and the sweeps (gpurun_out/exp7.txt, exp8.txt:
+    // teapot +9 % in f64 and f32 at 8 / 40; book1 and the 1M-sphere scene lose 1-2 % there) favour shorter rounds and
+    // an earlier exit.  CRUCIBLE_WALK_ROUND / CRUCIBLE_WALK_EXIT override.
+    int walk_round_steps = -1;         // wrappers a lane may step through per round; 0 = until every walking lane found a leaf or ran out
+    int walk_exit_lanes = -1;          // leave the walk phase once this many lanes are not walking (64 = wait for all)
     int last_block = 0, last_grid = 0;
     bool check_abort = false;          // the last launch was a queue kernel whose abort word has not been read yet
 };
@@ -519,6 +525,7 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
     b.order.resize(n);
     std::vector<Prim<real>> src(n);
     bool any_keys = false;
+    ds.has_triangles = false;
     for (int32_t i = 0; i < n; i++) {
         const CrPrimitive& p = h->prims[vis[i]];
         Prim<real>& q = src[i];
@@ -527,6 +534,7 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
         q.kind_mat = (p.kind & 1) | (p.material << 1);
         q.key_first = p.key_first; q.key_count = p.key_count;
         any_keys |= p.key_count > 0;
+        ds.has_triangles |= p.kind == CR_PRIM_TRIANGLE;
         b.order[i] = i;
         if (p.kind == CR_PRIM_SPHERE) {   // Sphere::new, sphere.rs:29-30; Aabb::new_from_points bvh.rs:44-64
             real r = q.g[3];
@@ -1069,8 +1077,8 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     a.work_counter = (uint32_t*)h->work_counter.p;
     a.counters = (uint64_t*)h->counters.p;
     a.out = (real*)d_out;
-    a.walk_exit_lanes = (uint32_t)h->walk_exit_lanes;
-    a.walk_round_steps = (uint32_t)h->walk_round_steps;
+    a.walk_exit_lanes = (uint32_t)(h->walk_exit_lanes >= 0 ? h->walk_exit_lanes : (ds.has_triangles ? 40 : 56));
+    a.walk_round_steps = (uint32_t)(h->walk_round_steps >= 0 ? h->walk_round_steps : (ds.has_triangles ? 8 : 10));
     a.sg_on = 0; a.sg_lw = a.sg_lh = 3; a.sg_groups = 0; a.sg_total = 0; a.sample_buf = nullptr;   // set by launch()
 
     const bool anim = ds.animated || c.animated;
@@ -1115,7 +1123,10 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, (latency ? h->latency_top_bytes : h->lds_top_bytes) / sizeof(Entry<real>));
     if (top > 0) {   // large scene: the top levels of the tree in LDS, everything else through L2
         a.lds_entries = top;
-        const size_t bytes = (size_t)top * sizeof(Entry<real>);
+        size_t bytes = (size_t)top * sizeof(Entry<real>);
+        // materials and textures ride along when they are small (the tree can be large with two materials)
+        const size_t side = (((size_t)ds.n_mats * sizeof(Mat<real>) + 15) & ~(size_t)15) + (((size_t)ds.n_texs * sizeof(Tex<real>) + 15) & ~(size_t)15);
+        if (side <= h->lds_side_limit) { a.lds_side = 1; bytes = ((bytes + 15) & ~(size_t)15) + side; }
         if constexpr (f32) if (latency) return anim ? launch<real, RES_TOP, true, false, true>(h, a, bytes, stats) : launch<real, RES_TOP, false, false, true>(h, a, bytes, stats);
         return anim ? launch<real, RES_TOP, true>(h, a, bytes, stats) : launch<real, RES_TOP, false>(h, a, bytes, stats);
     }
@@ -1238,6 +1249,7 @@ int32_t cr_create(int32_t device_id, CrHandle** out) {
     }
     if (const char* s = getenv("CRUCIBLE_LATENCY_ENTRIES")) h->latency_entries = (int32_t)std::max(0L, atol(s));
     if (const char* s = getenv("CRUCIBLE_LATENCY_TOP_KB")) h->latency_top_bytes = (size_t)std::max(0L, atol(s)) * 1024;
+    if (const char* s = getenv("CRUCIBLE_LDS_SIDE_KB")) h->lds_side_limit = (size_t)std::max(0L, atol(s)) * 1024;
     if (const char* s = getenv("CRUCIBLE_LDS_TOP_KB")) h->lds_top_bytes = (size_t)std::max(0L, atol(s)) * 1024;
     if (const char* s = getenv("CRUCIBLE_BLOCKS_PER_CU")) h->blocks_per_cu_override = atoi(s);
     if (const char* s = getenv("CRUCIBLE_BLOCK")) h->block_override = atoi(s);

@@ -216,6 +216,8 @@ template <typename real> struct KernelArgs {
     const Key<real>* cam_keys;   // this launch's camera keyframes (look_from keys, then look_at keys)
     int32_t n_entries, n_prims, n_mats, n_texs;
     int32_t lds_entries;      // entries staged in LDS (all of them, or the top levels of a large tree)
+    int32_t lds_side;         // RES_TOP: materials and textures follow the entry window in LDS (they are small even when
+                              // the tree is not: the teapot scenes have 2 materials), so shading reads no global tables
     int32_t sky_kind, sky_image;
     CamConst<real> cam;
     int32_t sample_begin, sample_end, samples_total, max_depth;
@@ -969,6 +971,13 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
             copy(A.mats, o2, (size_t)A.n_mats * sizeof(Mat<real>));
             copy(A.texs, o3, (size_t)A.n_texs * sizeof(Tex<real>));
             prims = (const Prim<real>*)(smem + o1);
+            mats = (const Mat<real>*)(smem + o2);
+            texs = (const Tex<real>*)(smem + o3);
+        } else if (A.lds_side) {   // RES_TOP: entry window | mats | texs
+            size_t o2 = (((size_t)A.lds_entries * sizeof(EntryT) + 15) & ~(size_t)15);
+            size_t o3 = o2 + (((size_t)A.n_mats * sizeof(Mat<real>) + 15) & ~(size_t)15);
+            copy(A.mats, o2, (size_t)A.n_mats * sizeof(Mat<real>));
+            copy(A.texs, o3, (size_t)A.n_texs * sizeof(Tex<real>));
             mats = (const Mat<real>*)(smem + o2);
             texs = (const Tex<real>*)(smem + o3);
         }
