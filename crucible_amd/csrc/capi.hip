@@ -116,6 +116,7 @@ struct CrHandle {
     // colour buffer may take up to sample_buf_limit bytes (more samples than fit are rendered in batches).
     int sample_granular = 1;             // CRUCIBLE_SAMPLE_GRANULAR=0: a lane owns a pixel (no buffer)
     size_t sample_buf_limit = (size_t)40 << 30;   // CRUCIBLE_SAMPLE_BUF_MB (MI355X: 288 GB of HBM)
+    int sg_chunk_override = 0;           // CRUCIBLE_SG_CHUNK: items per atomic (default: by launch size)
     int sg_lw = -1, sg_lh = -1;          // CRUCIBLE_SG_TILE=WxH (powers of two, W*H <= 64); default 4x4 pixels x 4 samples
     // f32 trees with more than latency_entries wrappers run on pathtrace_kernel_latency (6 waves/SIMD) with a
     // latency_top_bytes LDS window, three 512-thread groups per CU.  CRUCIBLE_LATENCY_ENTRIES (0 = never).
@@ -752,6 +753,13 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
             args.sample_begin = b0; args.sample_end = b1;
             args.sg_groups = groups_of(b1 - b0);
             args.sg_total = (uint32_t)((uint64_t)args.tiles_x * args.tiles_y * args.sg_groups * 64u);
+            {   // 1024 items per atomic keeps the counter quiet on long launches; a short launch (a small frame, or one
+                // GPU's shard of the samples) would end with whole chunks of imbalance, so a wave's chunk is at most
+                // 1/128 of its share
+                const uint64_t per_wave = (uint64_t)args.sg_total / std::max<uint64_t>(1, (uint64_t)grid * block / 64);
+                const uint64_t c = h->sg_chunk_override > 0 ? (uint64_t)h->sg_chunk_override : std::min<uint64_t>(1024, std::max<uint64_t>(64, per_wave / 128));
+                args.sg_chunk = (uint32_t)((c + 63) / 64 * 64);
+            }
             HIP_TRY(h, hipMemsetAsync(h->work_counter.p, 0, 4, h->stream));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(block), LDS ? lds_bytes : 0, h->stream, args);
             HIP_TRY(h, hipGetLastError());
@@ -1241,6 +1249,7 @@ int32_t cr_create(int32_t device_id, CrHandle** out) {
     if (const char* s = getenv("CRUCIBLE_LDS_LIMIT")) h->lds_limit = (size_t)atol(s);
     if (const char* s = getenv("CRUCIBLE_SAMPLE_GRANULAR")) h->sample_granular = atoi(s) != 0;
     if (const char* s = getenv("CRUCIBLE_SAMPLE_BUF_MB")) h->sample_buf_limit = (size_t)std::max(0L, atol(s)) << 20;
+    if (const char* s = getenv("CRUCIBLE_SG_CHUNK")) h->sg_chunk_override = std::max(0, atoi(s));
     if (const char* s = getenv("CRUCIBLE_SG_TILE")) {
         int tw = 0, th = 0;
         if (sscanf(s, "%dx%d", &tw, &th) == 2 && tw > 0 && th > 0 && (tw & (tw - 1)) == 0 && (th & (th - 1)) == 0 && tw * th <= 64) {

@@ -234,6 +234,7 @@ template <typename real> struct KernelArgs {
     // written by one wave (they merge in that XCD's L2 into whole lines), and sg_finalize_kernel adds them in order.
     uint32_t sg_on, sg_lw, sg_lh, sg_groups;
     uint32_t sg_total;        // work items of the launch (tiles * sg_groups * 64)
+    uint32_t sg_chunk;        // work items a wave takes per atomic on the counter (a multiple of 64)
     real* sample_buf;
     uint64_t* counters;       // [0] segments [1] node tests [2] prim tests [3] texel fetches
     real* att_stack;          // max_depth * n_threads records of 3 reals, level-major
@@ -990,7 +991,7 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
     const CamConst<real>& cam = A.cam;
     // sample-granular mode: the wave's private slice [wv_next, wv_end) of the work counter (same value in all lanes)
     uint32_t wv_next = 0, wv_end = 0;
-    constexpr uint32_t SG_CHUNK = 1024;
+    const uint32_t SG_CHUNK = A.sg_chunk;   // items a wave takes per atomic: 1024 for long launches, fewer for short ones (launch())
 
     int state = ST_NEED_PIXEL;
     uint32_t pix_i = 0, pix_j = 0;
