@@ -1569,9 +1569,13 @@ int32_t cr_group_create(const int32_t* device_ids, int32_t n_devices, CrGroup** 
     if (!out) return gfail(nullptr, CR_ERR_INVALID_ARG, "out is null");
     *out = nullptr;
     if (!device_ids || n_devices < 1) return gfail(nullptr, CR_ERR_INVALID_ARG, "device list is empty");
+    // CRUCIBLE_GROUP_SAME_DEVICE=1 (tests on a one-GPU box): the members may share a device; their sums are then added
+    // by a plain kernel instead of RCCL, which refuses two ranks on one device.  Everything else is the real path.
+    const bool same_device = getenv("CRUCIBLE_GROUP_SAME_DEVICE") != nullptr;
     for (int i = 0; i < n_devices; i++) for (int j = 0; j < i; j++)
-        if (device_ids[i] == device_ids[j]) return gfail(nullptr, CR_ERR_INVALID_ARG, "a device appears twice in the list");
+        if (device_ids[i] == device_ids[j] && !same_device) return gfail(nullptr, CR_ERR_INVALID_ARG, "a device appears twice in the list");
     CrGroup* g = new CrGroup();
+    g->same_device_sum = same_device && n_devices > 1;
     g->world = n_devices; g->first = 0;
     g->members.assign((size_t)n_devices, nullptr);
     g->partial.resize((size_t)n_devices);
@@ -1580,7 +1584,7 @@ int32_t cr_group_create(const int32_t* device_ids, int32_t n_devices, CrGroup** 
         if (rc != CR_OK) { g_group_create_error = g_create_error; group_free(g); return rc; }
     }
     const bool force = getenv("CRUCIBLE_GROUP_FORCE_RCCL") != nullptr;   // tests: exercise the collective on one device
-    if (n_devices > 1 || force) {
+    if ((n_devices > 1 || force) && !g->same_device_sum) {
         RcclApi& api = rccl_api();
         if (!api.lib) { g_group_create_error = api.error; group_free(g); return CR_ERR_UNSUPPORTED; }
         g->comms.assign((size_t)n_devices, nullptr);
@@ -1681,6 +1685,15 @@ int32_t cr_group_render(CrGroup* g, const CrCameraDesc* cam, const CrRenderParam
     if (g->world > 1 || collective) {
         CrHandle* root = g->members[0];
         if (root_here) { GHIP_TRY(g, hipSetDevice(root->device)); GHIP_TRY(g, hipEventRecord(g->ev0, root->stream)); }
+        if (g->same_device_sum) {   // every member is on the root's device: wait for their renders, then add in member order
+            for (int i = 1; i < local; i++) GHIP_TRY(g, hipStreamSynchronize(g->members[(size_t)i]->stream));
+            const unsigned grid = (unsigned)((n + 255) / 256);
+            for (int i = 1; i < local; i++) {
+                if (f64) hipLaunchKernelGGL((group_add_kernel<double>), dim3(grid), dim3(256), 0, root->stream, (double*)g->partial[0].p, (const double*)g->partial[(size_t)i].p, n);
+                else hipLaunchKernelGGL((group_add_kernel<float>), dim3(grid), dim3(256), 0, root->stream, (float*)g->partial[0].p, (const float*)g->partial[(size_t)i].p, n);
+            }
+            GHIP_TRY(g, hipGetLastError());
+        }
         if (collective) {
             RcclApi& api = rccl_api();
             const ncclDataType_t dt = f64 ? ncclDouble : ncclFloat;

@@ -57,6 +57,14 @@ RcclApi& rccl_api() {
 
 thread_local std::string g_group_create_error;
 
+// Test-only stand-in for the collective when several members share ONE device (CRUCIBLE_GROUP_SAME_DEVICE=1: RCCL
+// refuses two ranks on a device): acc += part, member by member in index order.
+template <typename real>
+__global__ void __launch_bounds__(256) group_add_kernel(real* acc, const real* part, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] = acc[i] + part[i];
+}
+
 template <typename real>
 __global__ void __launch_bounds__(256) group_mean_kernel(const real* sum, real* out, size_t n, real cnt) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -68,6 +76,7 @@ __global__ void __launch_bounds__(256) group_mean_kernel(const real* sum, real* 
 struct CrGroup {
     std::vector<CrHandle*> members;    // driven by this process
     std::vector<ncclComm_t> comms;     // one per local member; empty: no collective (one-member group)
+    bool same_device_sum = false;      // tests: members share a device and their sums are added by group_add_kernel
     std::vector<DevBuf> partial;       // per local member: W*H*3 raw sums of its shard
     int first = 0;                     // group-wide index of members[0]
     int world = 1;                     // members in the whole group

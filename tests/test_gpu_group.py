@@ -74,3 +74,37 @@ def test_group_handles_drive_frame_sharding(renderer):
         assert np.array_equal(t.cpu().numpy(), ref)
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+@pytest.mark.parametrize("members,spp", [(2, 6), (4, 10), (8, 5)])
+def test_several_members_on_one_device(renderer, monkeypatch, rt, tag, members, spp):
+    """The whole multi-member path on the one GPU of this box: CRUCIBLE_GROUP_SAME_DEVICE lets the members share the
+    device and replaces only the ncclReduce by an add kernel (RCCL refuses two ranks on one device).  Shard split,
+    per-member handles and streams, sum in member order, divide by spp: the result equals the shard sums added in the
+    same order bit for bit, and the 1-GPU image within re-association error; (8, 5) has empty shards."""
+    from crucible_amd.group import shard
+    monkeypatch.setenv("CRUCIBLE_GROUP_SAME_DEVICE", "1")
+    sc = book1_end_scene(1, scene_seed=1, image_width=80, samples=spp)
+    cam = sc.scene_cam
+    renderer.upload_scene(sc.flatten())
+    total = None
+    for m in range(members):
+        b, n = shard(spp, m, members)
+        part, _ = renderer.render(cam, seed=SEED, real_type=rt, sample_begin=b, sample_count=n, output_sum=True)
+        total = part.copy() if total is None else total + part
+    expect = total / total.dtype.type(spp)
+    single, sst = renderer.render(cam, seed=SEED, real_type=rt)
+    g = RenderGroup.local([0] * members)
+    try:
+        assert (g.size, g.local_size) == (members, members)
+        g.upload_scene(sc.flatten())
+        img, st = g.render(cam, seed=SEED, real_type=rt)
+        assert st["members"] == members and st["used_rccl"] == 0
+        assert np.array_equal(img, expect)
+        assert np.abs(img.astype(np.float64) - single).max() < (1e-5 if rt == A.CR_REAL_F32 else 1e-14)
+        for k in COUNTERS:
+            assert st[k] == sst[k], k      # the union of the shards is the 1-GPU sample set
+        assert st["samples"] == 80 * 45 * spp
+    finally:
+        g.close()
