@@ -55,6 +55,7 @@ template <typename E> constexpr size_t entry_pad() { return (sizeof(E) & (sizeof
 template <typename real> struct DevScene {
     bool built = false;
     DevBuf entries, prims, mats, texs, keys;
+    DevBuf leaf_runs;                        // (first, count) of the primitive runs that leaves holding a list name
     int32_t n_entries = 0, n_prims = 0, n_mats = 0, n_texs = 0, n_scene_keys = 0;
     size_t lds_bytes = 0;
     bool animated = false;
@@ -64,9 +65,9 @@ template <typename real> struct DevScene {
     size_t entry_bytes = sizeof(Entry<real>);
     std::vector<int8_t> host_axis;           // ordered: split axis per wrapper (-1 leaf), same order as host_entries
     std::vector<int32_t> level_begin;        // entries of tree level l are [level_begin[l], level_begin[l+1])
-    std::vector<Entry<real>> host_entries;   // what the device walks (for cr_export_bvh)
+    std::vector<Entry<real>> host_entries;   // the tree over the scene's objects (for cr_export_bvh); the device copy names primitive runs
     std::vector<int32_t> leaf_desc;          // leaf-order position -> index in the caller's primitive list
-    void release() { entries.release(); entries_refit.release(); prims.release(); mats.release(); texs.release(); keys.release(); built = false; }
+    void release() { entries.release(); entries_refit.release(); leaf_runs.release(); prims.release(); mats.release(); texs.release(); keys.release(); built = false; }
 };
 
 }   // namespace
@@ -420,9 +421,9 @@ int32_t run_box_kernels(CrHandle* h, DevScene<real>& ds, void* entries, real ta,
         if (end <= begin) continue;
         const dim3 grid((unsigned)((end - begin + 255) / 256)), block(256);
         if (ds.ordered) hipLaunchKernelGGL((refit_level_kernel<real, true>), grid, block, 0, h->stream, (EntryO<real>*)entries, begin, end,
-                                           (const Prim<real>*)ds.prims.p, (const Key<real>*)ds.keys.p, ta, tb, use_keys ? 1 : 0);
+                                           (const Prim<real>*)ds.prims.p, (const Key<real>*)ds.keys.p, ta, tb, use_keys ? 1 : 0, (const int32_t*)ds.leaf_runs.p);
         else hipLaunchKernelGGL((refit_level_kernel<real, false>), grid, block, 0, h->stream, (Entry<real>*)entries, begin, end,
-                                (const Prim<real>*)ds.prims.p, (const Key<real>*)ds.keys.p, ta, tb, use_keys ? 1 : 0);
+                                (const Prim<real>*)ds.prims.p, (const Key<real>*)ds.keys.p, ta, tb, use_keys ? 1 : 0, (const int32_t*)ds.leaf_runs.p);
     }
     HIP_TRY(h, hipGetLastError());
     return CR_OK;
@@ -517,38 +518,77 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
     auto t_begin = std::chrono::steady_clock::now();
     const bool timing = getenv("CRUCIBLE_BUILD_TIMING") != nullptr;
     auto lap = [&](const char* what) { if (timing) fprintf(stderr, "[build] %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };
-    // visible primitives, in list order (bvhwrapper.rs:16-26)
-    std::vector<int32_t> vis;
-    for (size_t i = 0; i < h->prims.size(); i++) if (!(h->prims[i].flags & CR_PRIM_HIDDEN)) vis.push_back((int32_t)i);
-    const int32_t n = (int32_t)vis.size();
+    // The objects the BVH build sees, in list order (bvhwrapper.rs:16-26): visible spheres and triangles, and every
+    // list whatever it holds.  Under the opt-in trees a list's visible objects stand in for it.
+    struct Obj { int32_t desc, first, count; };   // count < 0: a primitive
+    const bool ref_tree = h->bvh_mode == CR_BVH_REFERENCE;
+    std::vector<Obj> objs;
+    for (size_t i = 0; i < h->prims.size(); i++) {
+        const CrPrimitive& p = h->prims[i];
+        if (p.flags & CR_PRIM_MEMBER) continue;
+        if (p.kind == CR_PRIM_LIST) {
+            const int32_t first = (int32_t)p.v[0], count = (int32_t)p.v[1];
+            if (ref_tree) objs.push_back({(int32_t)i, first, count});
+            else for (int32_t k = first; k < first + count; k++) if (!(h->prims[k].flags & CR_PRIM_HIDDEN)) objs.push_back({k, 0, -1});
+        } else if (!(p.flags & CR_PRIM_HIDDEN)) objs.push_back({(int32_t)i, 0, -1});
+    }
+    const int32_t n = (int32_t)objs.size();
     Builder<real> b;
     for (int a = 0; a < 3; a++) { b.bmin[a].resize(n); b.bmax[a].resize(n); }
     b.order.resize(n);
     std::vector<Prim<real>> src(n);
-    bool any_keys = false;
+    bool any_keys = false, any_lists = false;
     ds.has_triangles = false;
-    for (int32_t i = 0; i < n; i++) {
-        const CrPrimitive& p = h->prims[vis[i]];
-        Prim<real>& q = src[i];
+    auto make_prim = [&](const CrPrimitive& p) {
+        Prim<real> q;
+        memset(&q, 0, sizeof q);
         for (int k = 0; k < 9; k++) q.g[k] = (real)p.v[k];
         if (p.kind == CR_PRIM_SPHERE) q.g[4] = real(1) / q.g[3];    // 1/radius, used for the hit normal of static spheres
         q.kind_mat = (p.kind & 1) | (p.material << 1);
         q.key_first = p.key_first; q.key_count = p.key_count;
         any_keys |= p.key_count > 0;
         ds.has_triangles |= p.kind == CR_PRIM_TRIANGLE;
-        b.order[i] = i;
-        if (p.kind == CR_PRIM_SPHERE) {   // Sphere::new, sphere.rs:29-30; Aabb::new_from_points bvh.rs:44-64
-            real r = q.g[3];
+        return q;
+    };
+    auto prim_box = [](const Prim<real>& q, real lo[3], real hi[3]) {
+        if (q.kind() == CR_PRIM_SPHERE) {   // Sphere::new, sphere.rs:29-30; Aabb::new_from_points bvh.rs:44-64
+            const real r = q.g[3];
             for (int a = 0; a < 3; a++) {
-                real lo = q.g[a] + (-r), hi = q.g[a] + r;
-                if (lo <= hi) { b.bmin[a][i] = lo; b.bmax[a][i] = hi; } else { b.bmin[a][i] = hi; b.bmax[a][i] = lo; }
+                const real l = q.g[a] + (-r), u = q.g[a] + r;
+                if (l <= u) { lo[a] = l; hi[a] = u; } else { lo[a] = u; hi[a] = l; }
             }
-        } else {                          // Triangle::new, triangle.rs:28-35 (f64::min/max)
+        } else {                            // Triangle::new, triangle.rs:28-35 (f64::min/max)
             for (int a = 0; a < 3; a++) {
-                b.bmax[a][i] = std::fmax(q.g[a], std::fmax(q.g[3 + a], q.g[6 + a]));
-                b.bmin[a][i] = std::fmin(q.g[a], std::fmin(q.g[3 + a], q.g[6 + a]));
+                hi[a] = std::fmax(q.g[a], std::fmax(q.g[3 + a], q.g[6 + a]));
+                lo[a] = std::fmin(q.g[a], std::fmin(q.g[3 + a], q.g[6 + a]));
             }
         }
+    };
+    for (int32_t i = 0; i < n; i++) {
+        const Obj& o = objs[i];
+        b.order[i] = i;
+        real lo[3], hi[3];
+        if (o.count < 0) {
+            src[i] = make_prim(h->prims[o.desc]);
+            prim_box(src[i], lo, hi);
+        } else {   // HitList: Aabb::default() (hitlist.rs:13-18), grown by add() over every object, hidden or not (hitlist.rs:24-27)
+            any_lists = true;
+            for (int a = 0; a < 3; a++) { lo[a] = std::numeric_limits<real>::infinity(); hi[a] = -std::numeric_limits<real>::infinity(); }
+            if (!(h->prims[o.desc].flags & CR_LIST_EMPTY_BOX))
+                for (int32_t k = o.first; k < o.first + o.count; k++) {
+                    CrPrimitive m = h->prims[k];
+                    Prim<real> q;
+                    for (int j = 0; j < 9; j++) q.g[j] = (real)m.v[j];
+                    q.kind_mat = m.kind & 1;
+                    real ml[3], mh[3];
+                    prim_box(q, ml, mh);
+                    for (int a = 0; a < 3; a++) {   // Interval::tight_enclose, utils.rs:631-635
+                        lo[a] = lo[a] <= ml[a] ? lo[a] : ml[a];
+                        hi[a] = hi[a] >= mh[a] ? hi[a] : mh[a];
+                    }
+                }
+        }
+        for (int a = 0; a < 3; a++) { b.bmin[a][i] = lo[a]; b.bmax[a][i] = hi[a]; }
     }
     std::vector<int8_t> axis;
     ds.ordered = h->bvh_mode == CR_BVH_SAH_ORDERED;
@@ -566,8 +606,34 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
     } else if (n > 0) { b.build_root(n); relayout_bfs(b.entries, ds.level_begin); }
     else ds.level_begin.assign(1, 0);
     lap("tree");
-    std::vector<Prim<real>> leaf_prims(n);
-    for (int32_t i = 0; i < n; i++) leaf_prims[i] = src[b.order[i]];
+    // Primitive records in leaf order; a list contributes its visible objects in the list's order (a hidden object
+    // returns no hit before anything is computed: sphere.rs:62, triangle.rs:87).
+    std::vector<Prim<real>> leaf_prims;
+    leaf_prims.reserve(n);
+    std::vector<int32_t> first_of((size_t)n + 1);
+    for (int32_t i = 0; i < n; i++) {
+        const Obj& o = objs[b.order[i]];
+        first_of[i] = (int32_t)leaf_prims.size();
+        if (o.count < 0) leaf_prims.push_back(src[b.order[i]]);
+        else for (int32_t k = o.first; k < o.first + o.count; k++) if (!(h->prims[k].flags & CR_PRIM_HIDDEN)) leaf_prims.push_back(make_prim(h->prims[k]));
+    }
+    first_of[n] = (int32_t)leaf_prims.size();
+    if (leaf_prims.size() >= ((size_t)1 << 29)) return fail(h, CR_ERR_INVALID_ARG, "too many primitives");
+    // What the device walks: a leaf wrapper names a run of primitive records.  One or two records fit the wrapper
+    // itself; a leaf that holds a list names its run through the side table (first, count).
+    std::vector<Entry<real>> dev_entries;
+    std::vector<int32_t> leaf_runs;
+    if (any_lists) {
+        dev_entries = b.entries;
+        for (Entry<real>& e : dev_entries) {
+            if (e.leaf < 0) continue;
+            const int32_t start = e.leaf >> 1, span = (e.leaf & 1) + 1;
+            const int32_t first = first_of[start], count = first_of[start + span] - first;
+            if (count == 1 || count == 2) e.leaf = (first << 1) | (count - 1);
+            else { e.leaf = kLeafRun | (int32_t)(leaf_runs.size() / 2); leaf_runs.push_back(first); leaf_runs.push_back(count); }
+        }
+    }
+    const std::vector<Entry<real>>& up_entries = any_lists ? dev_entries : b.entries;
 
     // Device texture table: only textures a non-solid lambertian can reach (a solid top-level
     // texture is folded into its material), re-indexed densely; children keep smaller indices.
@@ -649,12 +715,13 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
         }
         HIP_TRY(h, up(ds.entries, eo.data(), eo.size() * sizeof(EntryO<real>), entry_pad<EntryO<real>>()));
     } else
-    HIP_TRY(h, up(ds.entries, b.entries.data(), b.entries.size() * sizeof(Entry<real>), entry_pad<Entry<real>>()));
+    HIP_TRY(h, up(ds.entries, up_entries.data(), up_entries.size() * sizeof(Entry<real>), entry_pad<Entry<real>>()));
+    HIP_TRY(h, up(ds.leaf_runs, leaf_runs.data(), leaf_runs.size() * sizeof(int32_t)));
     HIP_TRY(h, up(ds.prims, leaf_prims.data(), leaf_prims.size() * sizeof(Prim<real>)));
     HIP_TRY(h, up(ds.mats, mats.data(), mats.size() * sizeof(Mat<real>)));
     HIP_TRY(h, up(ds.texs, texs.data(), texs.size() * sizeof(Tex<real>)));
     HIP_TRY(h, up(ds.keys, keys.data(), keys.size() * sizeof(Key<real>)));
-    ds.n_entries = (int32_t)b.entries.size(); ds.n_prims = n; ds.n_mats = (int32_t)mats.size(); ds.n_texs = (int32_t)texs.size();
+    ds.n_entries = (int32_t)b.entries.size(); ds.n_prims = (int32_t)leaf_prims.size(); ds.n_mats = (int32_t)mats.size(); ds.n_texs = (int32_t)texs.size();
     ds.n_scene_keys = (int32_t)h->keys.size();
     auto r16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     ds.lds_bytes = r16(b.entries.size() * ds.entry_bytes) + r16(leaf_prims.size() * sizeof(Prim<real>)) +
@@ -670,7 +737,7 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
     ds.host_entries = b.entries;
     ds.host_axis = axis;
     ds.leaf_desc.resize(n);
-    for (int32_t i = 0; i < n; i++) ds.leaf_desc[i] = vis[b.order[i]];
+    for (int32_t i = 0; i < n; i++) ds.leaf_desc[i] = objs[b.order[i]].desc;
     ds.built = true;
     h->upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return CR_OK;
@@ -882,6 +949,9 @@ int32_t wf_run(CrHandle* h, WfArgs<real>& W, size_t lds_bytes, int32_t s_begin, 
     HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 64 * sizeof(uint64_t), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->wf_acc.p, 0, npix * 3 * sizeof(real), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->wf_job.p, 0xFF, (size_t)W.n_slots * 4, h->stream));
+    // no slot may look like it holds a ray before the logic kernel gives it one: recycled device memory can hold
+    // WF_PENDING from an earlier handle, and extend would walk that slot's stale ray (extra node tests, same image)
+    HIP_TRY(h, hipMemsetAsync(h->wf_hit_prim.p, 0, (size_t)W.n_slots * 4, h->stream));
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     int iterations = 0;
     const int LAG = 4, RING = 8;
@@ -1013,7 +1083,7 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     }
     KernelArgs<real> a;
     memset(&a, 0, sizeof a);
-    a.entries = (const Entry<real>*)ds.entries.p; a.prims = (const Prim<real>*)ds.prims.p;
+    a.entries = (const Entry<real>*)ds.entries.p; a.prims = (const Prim<real>*)ds.prims.p; a.leaf_runs = (const int32_t*)ds.leaf_runs.p;
     const bool refit = p->refit_boxes && ds.animated && ds.n_entries > 0;   // without primitive keys the boxes would not change
     a.mats = (const Mat<real>*)ds.mats.p; a.texs = (const Tex<real>*)ds.texs.p;
     a.images = (const ImageRef*)h->images.p; a.texels = (const uint32_t*)h->texels.p;
@@ -1300,7 +1370,7 @@ int32_t cr_upload_scene(CrHandle* h, const CrSceneDesc* s) {
     if (!s) return fail(h, CR_ERR_INVALID_ARG, "scene is null");
     if (s->n_prims < 0 || s->n_materials < 0 || s->n_textures < 0 || s->n_images < 0 || s->n_keys < 0)
         return fail(h, CR_ERR_INVALID_ARG, "negative count");
-    if (s->n_prims >= (1 << 30)) return fail(h, CR_ERR_INVALID_ARG, "too many primitives");
+    if (s->n_prims >= (1 << 29)) return fail(h, CR_ERR_INVALID_ARG, "too many primitives");
     auto finite = [](double x) { return x == x && x != HUGE_VAL && x != -HUGE_VAL; };
     for (int i = 0; i < s->n_textures; i++) {
         const CrTexture& t = s->textures[i];
@@ -1337,8 +1407,29 @@ int32_t cr_upload_scene(CrHandle* h, const CrSceneDesc* s) {
         if (k.channel < CR_KEY_TX || k.channel > CR_KEY_SCALE_Z || (k.interp != CR_KEY_NERP && k.interp != CR_KEY_LERP))
             return fail(h, CR_ERR_INVALID_ARG, "bad keyframe");
     }
+    {   // lists (CR_PRIM_LIST): whole-number ranges of flagged spheres/triangles, every flagged primitive in exactly one
+        std::vector<char> owned((size_t)std::max(0, s->n_prims), 0);
+        for (int i = 0; i < s->n_prims; i++) {
+            const CrPrimitive& p = s->prims[i];
+            if (p.kind != CR_PRIM_LIST) continue;
+            if (p.flags & (CR_PRIM_MEMBER | CR_PRIM_HIDDEN)) return fail(h, CR_ERR_INVALID_ARG, "a list is a scene element: it cannot be hidden or be an object of a list");
+            const double first = p.v[0], count = p.v[1];
+            if (!(first >= 0.0 && count >= 0.0 && first == std::floor(first) && count == std::floor(count) && first + count <= (double)s->n_prims))
+                return fail(h, CR_ERR_INVALID_ARG, "list object range out of bounds");
+            for (int64_t k = (int64_t)first; k < (int64_t)(first + count); k++) {
+                const CrPrimitive& m = s->prims[k];
+                if ((m.kind != CR_PRIM_SPHERE && m.kind != CR_PRIM_TRIANGLE) || !(m.flags & CR_PRIM_MEMBER))
+                    return fail(h, CR_ERR_INVALID_ARG, "a list's objects must be spheres or triangles flagged CR_PRIM_MEMBER");
+                if (owned[(size_t)k]) return fail(h, CR_ERR_INVALID_ARG, "a primitive is an object of two lists");
+                owned[(size_t)k] = 1;
+            }
+        }
+        for (int i = 0; i < s->n_prims; i++)
+            if ((s->prims[i].flags & CR_PRIM_MEMBER) && !owned[(size_t)i]) return fail(h, CR_ERR_INVALID_ARG, "a primitive flagged CR_PRIM_MEMBER belongs to no list");
+    }
     for (int i = 0; i < s->n_prims; i++) {
         const CrPrimitive& p = s->prims[i];
+        if (p.kind == CR_PRIM_LIST) continue;
         if (p.kind != CR_PRIM_SPHERE && p.kind != CR_PRIM_TRIANGLE) return fail(h, CR_ERR_INVALID_ARG, "unknown primitive kind");
         if (p.material < 0 || p.material >= s->n_materials) return fail(h, CR_ERR_INVALID_ARG, "primitive material index out of range");
         if (p.key_count < 0 || p.key_first < 0 || p.key_first + p.key_count > s->n_keys) return fail(h, CR_ERR_INVALID_ARG, "primitive keyframe range out of bounds");

@@ -142,6 +142,9 @@ template <typename real> CR_HD V3<real> random_unit_vector(uint64_t& s) {   // u
 // wrappers BVHWrapper::hit visits, in the same order (left subtree, then right).
 // leaf < 0: inner wrapper, left child = -leaf.  leaf >= 0: span-1 or span-2 wrapper whose
 // children are primitives: first = leaf >> 1, count = (leaf & 1) + 1, in leaf order.
+// leaf >= 0 with kLeafRun set: a leaf that holds a HitList element; its primitives are the run
+// (first, count) = leaf_runs[2 * (leaf & ~kLeafRun)], [.. + 1] -- the list's visible objects and the wrapper's other
+// child in the order BVHWrapper::hit and HitList::hit visit them (bvhwrapper.rs:108-120, hitlist.rs:55-61).
 // Entries are stored level by level (BFS), so the first K entries are the top of the tree:
 // scenes too large for LDS keep those K in LDS and read the rest through L2.
 template <typename real> struct alignas(16) Entry {
@@ -163,6 +166,7 @@ template <typename real> struct alignas(16) EntryO {
 };
 template <typename real, bool ORD> struct EntryOf { using type = Entry<real>; };
 template <typename real> struct EntryOf<real, true> { using type = EntryO<real>; };
+constexpr int32_t kLeafRun = 0x40000000;
 CR_HD int32_t ordered_left(int32_t leaf) { return (-leaf) >> 2; }
 CR_HD int32_t ordered_near(int32_t leaf, int32_t oct) { const int32_t v = -leaf; return (v >> 2) + ((oct >> (v & 3)) & 1); }
 
@@ -214,6 +218,7 @@ template <typename real> struct KernelArgs {
     const uint32_t* texels;
     const Key<real>* keys;
     const Key<real>* cam_keys;   // this launch's camera keyframes (look_from keys, then look_at keys)
+    const int32_t* leaf_runs;    // (first, count) pairs for the leaves flagged kLeafRun
     int32_t n_entries, n_prims, n_mats, n_texs;
     int32_t lds_entries;      // entries staged in LDS (all of them, or the top levels of a large tree)
     int32_t lds_side;         // RES_TOP: materials and textures follow the entry window in LDS (they are small even when
@@ -904,6 +909,7 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
     if (leaf >= 0) {
         CR_DIAG_HIT(dg, DG_LEAFPH_WAVE, DG_LEAFPH_LANE);
         int32_t first = leaf >> 1, count = (leaf & 1) + 1;
+        if (leaf & kLeafRun) { first = A.leaf_runs[2 * (leaf & ~kLeafRun)]; count = A.leaf_runs[2 * (leaf & ~kLeafRun) + 1]; }
         for (int32_t k = 0; k < count; k++) {
             const Prim<real>& p = prims[first + k];
             c_prim++;

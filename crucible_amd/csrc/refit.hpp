@@ -151,14 +151,15 @@ CR_HD void prim_box_over(const Prim<real>& p, const Key<real>* keys, real ta, re
 // use_keys = 0 gives the construction-time boxes (how the LBVH builder fills in its boxes).
 template <typename real, bool ORD>
 __global__ void refit_level_kernel(typename EntryOf<real, ORD>::type* entries, int32_t begin, int32_t end, const Prim<real>* prims,
-                                   const Key<real>* keys, real ta, real tb, int32_t use_keys) {
+                                   const Key<real>* keys, real ta, real tb, int32_t use_keys, const int32_t* leaf_runs) {
     const int32_t i = begin + (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= end) return;
     const int32_t leaf = entries[i].leaf;
     real lo[3], hi[3];
     for (int a = 0; a < 3; a++) { lo[a] = r_inf(real(0)); hi[a] = -r_inf(real(0)); }
     if (leaf >= 0) {
-        const int32_t first = leaf >> 1, count = (leaf & 1) + 1;
+        int32_t first = leaf >> 1, count = (leaf & 1) + 1;
+        if (leaf & kLeafRun) { first = leaf_runs[2 * (leaf & ~kLeafRun)]; count = leaf_runs[2 * (leaf & ~kLeafRun) + 1]; }
         for (int32_t k = 0; k < count; k++) prim_box_over(prims[first + k], keys, ta, tb, lo, hi, use_keys != 0);
     } else {
         const int32_t li = ORD ? ordered_left(leaf) : -leaf;   // siblings are adjacent in the level-order array

@@ -155,6 +155,37 @@ def scaled_teapot(threads=1, image_width=400, samples=200, sky=None):
     return sc
 
 
+def teapot_as_list(threads=1, image_width=400, samples=200):
+    """Not in the reference's demos: the teapot handed to the scene as ONE HitList element (what
+    `scene.add_element(Hittables::HitList(load_obj(..)), ..)` gives, scene/mod.rs:164-166) next to a HitList::new(vec)
+    list (empty box), a list inside a list with a hidden object, and ordinary elements."""
+    from .scene import HitList, load_obj
+    sc = Scene.new_image(16.0 / 9.0, image_width, 24, 180.0, threads)
+    cam = sc.scene_cam
+    cam.set_samples(samples)
+    cam.set_max_depth(50)
+    cam.look_from((13.0, 10.0, 3.0))
+    cam.look_at((0.0, 0.0, 0.0))
+    cam.set_vfov(20.0)
+    cam.set_defocus_angle(0.6)
+    cam.set_focus_dist(10.0)
+    sc.add_element(load_obj("teapot.obj", 0.5, (0.0, 0.0, 0.0), Metal.new((0.8, 0.3, 0.5), 0.05)), "teapot")
+    sc.add_element(Sphere.new((0.0, -1000.0, 0.0), 1000.0, _checker_ground()), "ground")
+    glass, matte = Dielectric.new(1.5), Lambertian.new_from_color((0.2, 0.4, 0.8), 1.0)
+    sc.add_element(HitList.new([Sphere.new((2.5, 0.5, 2.0), 0.5, glass), Sphere.new((3.4, 0.3, 1.2), 0.3, matte)]), "loose")
+    inner = HitList.default()
+    inner.add(Sphere.new((-2.0, 0.4, 2.5), 0.4, matte))
+    hidden = Sphere.new((-2.0, 1.2, 2.5), 0.4, glass)
+    hidden.hide = True
+    inner.add(hidden)
+    outer = HitList.default()
+    outer.add(Sphere.new((-3.0, 0.5, 1.5), 0.5, Metal.new((0.8, 0.8, 0.8), 0.0)))
+    outer.add(inner)
+    sc.add_element(outer, "outer")
+    sc.add_element(HitList.default(), "nothing")
+    return sc
+
+
 def earth(threads=1, image_width=400, samples=500, image=None):
     """demo_images.rs:202-221; `image` replaces earthmap.jpg with an in-memory RTWImage."""
     sc = Scene.new_image(16.0 / 9.0, image_width, 24, 180.0, threads)

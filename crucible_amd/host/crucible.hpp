@@ -226,13 +226,47 @@ struct Materials {
 };
 
 // ---------------------------------------------------------------- objects
-struct Hittables {   // Hittables::{Sphere,Triangle}
+struct Hittables {   // Hittables::{Sphere,Triangle,HitList}
     int kind = CR_PRIM_SPHERE;
     size_t id = 0;
     bool hide = false;
     double v[9] = {0};
     MaterialPtr mat;
     TransformTimeline timeline;
+    // HitList (objects/hitlist.rs).  As a scene element (scene/mod.rs:164-166) the BVH build treats it as one object
+    // whose box is what add() accumulated: new(objs) leaves Aabb::default() (:13-18), clear() keeps the old box (:20-22).
+    // The C ABI can say "empty box" or "union of the objects"; a list inside a list is passed as its objects spliced
+    // in place (the inner box is never read by a hit).  Other mixtures make flatten() throw.
+    std::vector<Hittables> objs;
+    size_t n_new = 0, n_added = 0;
+    bool stale_box = false;
+    static Hittables hit_list(std::vector<Hittables> objs = {}) {   // HitList::new / HitList::default
+        Hittables h; h.kind = CR_PRIM_LIST; h.id = (size_t)-1; h.objs = std::move(objs); h.n_new = h.objs.size();
+        return h;
+    }
+    void add(Hittables o) { need_list(); objs.push_back(std::move(o)); n_added++; }   // :24-27 (the object is cloned: later edits do not reach it)
+    void clear() { need_list(); stale_box = stale_box || n_added > 0; objs.clear(); n_new = 0; }
+    const std::vector<Hittables>& get_objs() const { return objs; }
+    bool box_is_default() const { return n_added == 0 && !stale_box; }
+    bool box_is_union() const {
+        if (stale_box || n_new != 0) return false;
+        for (const Hittables& o : objs) if (o.kind == CR_PRIM_LIST && !o.box_is_union()) return false;
+        return true;
+    }
+    // the spheres and triangles under this list in visiting order; *empty_box = the descriptor's CR_LIST_EMPTY_BOX
+    void spliced(std::vector<const Hittables*>& out, bool* empty_box) const {
+        need_list();
+        collect(out);
+        if (box_is_default()) *empty_box = true;
+        else if (box_is_union()) *empty_box = false;
+        else throw std::invalid_argument("this HitList's box is neither Aabb::default() nor the union of its objects: not representable");
+    }
+private:
+    void need_list() const { if (kind != CR_PRIM_LIST) throw std::invalid_argument("not a HitList"); }
+    void collect(std::vector<const Hittables*>& out) const {
+        for (const Hittables& o : objs) { if (o.kind == CR_PRIM_LIST) o.collect(out); else out.push_back(&o); }
+    }
+public:
     static Hittables sphere(Point3 c, double radius, MaterialPtr m) {   // Sphere::new, sphere.rs:25-39
         if (!(radius >= 0.0)) throw std::invalid_argument("Cannot make a sphere with negative radius");
         Hittables h; h.kind = CR_PRIM_SPHERE; h.v[0] = c.x; h.v[1] = c.y; h.v[2] = c.z; h.v[3] = radius; h.mat = m;
@@ -390,6 +424,7 @@ public:
     void load_default_skybox() { skybox.reset(); }
     void load_spherical_skybox(std::shared_ptr<RTWImage> im) { skybox = im; }
     void add_element(Hittables e, const std::string& alias) {   // scene/mod.rs:159-188
+        if (e.kind == CR_PRIM_LIST) { elements.push_back(std::move(e)); return; }   // :164-166: kept as it is, the alias is not registered
         e.id = vend_id(alias, e.kind == CR_PRIM_SPHERE ? "Sphere" : "Triangle");
         elements.push_back(std::move(e));
     }
@@ -469,12 +504,23 @@ public:
             f.materials.push_back(rec);
             return mat_ids[m.get()] = id;
         };
-        for (const Hittables& e : elements) {
+        auto emit = [&](const Hittables& e, int32_t extra_flags) {
             std::vector<CrKeyframe> ks = e.timeline.keyframes();
-            CrPrimitive p{e.kind, material_id(e.mat), e.hide ? CR_PRIM_HIDDEN : 0, (int32_t)f.keys.size(), (int32_t)ks.size(), 0, {0}};
+            CrPrimitive p{e.kind, material_id(e.mat), (e.hide ? CR_PRIM_HIDDEN : 0) | extra_flags, (int32_t)f.keys.size(), (int32_t)ks.size(), 0, {0}};
             std::copy(e.v, e.v + 9, p.v);
             f.prims.push_back(p);
             f.keys.insert(f.keys.end(), ks.begin(), ks.end());
+        };
+        for (const Hittables& e : elements) {
+            if (e.kind == CR_PRIM_LIST) {   // the list record, then its objects (crucible_hip.h CR_PRIM_LIST)
+                std::vector<const Hittables*> objs;
+                bool empty_box = false;
+                e.spliced(objs, &empty_box);
+                CrPrimitive p{CR_PRIM_LIST, 0, empty_box ? CR_LIST_EMPTY_BOX : 0, 0, 0, 0, {0}};
+                p.v[0] = (double)(f.prims.size() + 1); p.v[1] = (double)objs.size();
+                f.prims.push_back(p);
+                for (const Hittables* o : objs) emit(*o, CR_PRIM_MEMBER);
+            } else emit(e, 0);
         }
         int sky_kind = CR_SKY_DEFAULT, sky_image = -1;
         if (skybox) { sky_kind = CR_SKY_SPHERICAL; sky_image = image_id(skybox); }
@@ -701,6 +747,31 @@ inline Scene scaled_teapot(size_t threads, uint32_t image_width = 400, uint32_t 
     sc.translate_point(Point3{0.0, 0.4, 0.3}, 0.02, InterpolationType::LERP, TransformSpace::Local, "teapot");
     sc.scale_all_uniform(1.2, 0.05, InterpolationType::LERP, "teapot");
     sc.scale_z(0.7, 0.09, InterpolationType::LERP, "teapot");
+    return sc;
+}
+
+// Not in the reference's demos: the teapot handed to the scene as ONE HitList element (what
+// `scene.add_element(Hittables::HitList(load_obj(..)), ..)` gives, scene/mod.rs:164-166) next to a HitList::new(vec)
+// list (empty box), a list inside a list with a hidden object, and ordinary elements.
+inline Scene teapot_as_list(size_t threads, uint32_t image_width = 400, uint32_t samples = 200) {
+    Scene sc = Scene::new_image(16.0 / 9.0, image_width, 24, 180.0, threads);
+    book1_camera(sc.scene_cam, samples, Point3{13, 10, 3});
+    Hittables pot = Hittables::hit_list();
+    for (Hittables& t : load_obj("teapot.obj", 0.5, Point3{0, 0, 0}, Materials::metal(Color(0.8, 0.3, 0.5), 0.05))) pot.add(std::move(t));
+    sc.add_element(std::move(pot), "teapot");
+    sc.add_element(Hittables::sphere(Point3{0, -1000, 0}, 1000.0, checker_ground()), "ground");
+    MaterialPtr glass = Materials::dielectric(1.5), matte = Materials::lambertian(Color(0.2, 0.4, 0.8), 1.0);
+    sc.add_element(Hittables::hit_list({Hittables::sphere(Point3{2.5, 0.5, 2.0}, 0.5, glass), Hittables::sphere(Point3{3.4, 0.3, 1.2}, 0.3, matte)}), "loose");
+    Hittables inner = Hittables::hit_list();
+    inner.add(Hittables::sphere(Point3{-2.0, 0.4, 2.5}, 0.4, matte));
+    Hittables hidden = Hittables::sphere(Point3{-2.0, 1.2, 2.5}, 0.4, glass);
+    hidden.hide = true;
+    inner.add(hidden);
+    Hittables outer = Hittables::hit_list();
+    outer.add(Hittables::sphere(Point3{-3.0, 0.5, 1.5}, 0.5, Materials::metal(Color(0.8, 0.8, 0.8), 0.0)));
+    outer.add(inner);
+    sc.add_element(std::move(outer), "outer");
+    sc.add_element(Hittables::hit_list(), "nothing");
     return sc;
 }
 

@@ -89,6 +89,7 @@ int main(int argc, char** argv) {
                 case 2: return demo_builder::checkered_spheres(threads, w, samples > 0 ? (uint32_t)samples : 500);
                 case 3: return demo_builder::load_teapot(threads, w, samples > 0 ? (uint32_t)samples : 200);
                 case 6: return demo_builder::scaled_teapot(threads, w, samples > 0 ? (uint32_t)samples : 200);
+                case 7: return demo_builder::teapot_as_list(threads, w, samples > 0 ? (uint32_t)samples : 200);
                 case 5:
                     if (sky.empty()) throw std::invalid_argument("world 5 (garden_skybox) needs --sky FILE.hdr: garden.hdr is not shipped");
                     return demo_builder::garden_skybox(threads, RTWImage::load_hdr(sky), w, samples > 0 ? (uint32_t)samples : 500);

@@ -211,6 +211,72 @@ class Triangle:
     new = classmethod(lambda cls, a, b, c, m: cls(a, b, c, m))
 
 
+class HitList:
+    """objects/hitlist.rs.  As a scene element (scene/mod.rs:164-166) the BVH build treats it as one object whose
+    box is whatever `add` accumulated -- `new(objs)` leaves Aabb::default() (:13-18), `clear` keeps the old box
+    (:20-22) -- and a leaf wrapper holding it scans every object in order (:51-65).  A list inside a list is passed
+    as its objects spliced in place (the inner box is never read by a hit), which needs the outer box to be either
+    untouched by `add` or the union of everything spliced; other mixtures raise at flatten()."""
+
+    def __init__(self, objs=None):
+        self.id, self.hide, self.timeline = -1, False, None
+        self.objs = list(objs or [])
+        self._boxed = []          # what add() has folded into the box
+        self._stale_box = False   # clear() after add(): the box no longer describes the objects
+
+    new = classmethod(lambda cls, objs: cls(objs))
+    default = classmethod(lambda cls: cls())
+
+    def clear(self):
+        self._stale_box = self._stale_box or bool(self._boxed)
+        self.objs = []
+
+    def add(self, obj):
+        self.objs.append(obj)
+        self._boxed.append(obj)
+
+    def get_objs(self):
+        return self.objs
+
+    def __iter__(self):
+        return iter(self.objs)
+
+    def __len__(self):
+        return len(self.objs)
+
+    def __getitem__(self, i):
+        return self.objs[i]
+
+    def _box_is_union(self):
+        """The box equals the union of the boxes of every sphere/triangle under this list."""
+        if self._stale_box or len(self._boxed) != len(self.objs) or any(a is not b for a, b in zip(self._boxed, self.objs)):
+            return False
+        return all(o._box_is_union() for o in self.objs if isinstance(o, HitList))
+
+    def _box_is_default(self):
+        return not self._boxed and not self._stale_box
+
+    def spliced(self):
+        """(objects in visiting order, empty_box flag) -- or ValueError when the box is neither form."""
+        out = []
+
+        def walk(l):
+            for o in l.objs:
+                if isinstance(o, HitList):
+                    walk(o)
+                elif isinstance(o, (Sphere, Triangle)):
+                    out.append(o)
+                else:
+                    raise ValueError("a HitList element may hold spheres, triangles and lists (a BVHWrapper is not representable)")
+        walk(self)
+        if self._box_is_default():
+            return out, True
+        if self._box_is_union():
+            return out, False
+        # a box folded from only some of the objects, or from inner lists whose own boxes are not their union
+        raise ValueError("this HitList's box is neither Aabb::default() nor the union of its objects: not representable")
+
+
 def build_asset_path(asset_filename):
     """asset_loader/mod.rs:6-41: $ASSET_DIR is prepended verbatim; else `assets/` up to six levels up."""
     folder = os.environ.get("ASSET_DIR")
@@ -259,7 +325,10 @@ def load_obj(file, scale, shift, mat, strict=True):
             elif strict or not (parts[0].startswith("#") or parts[0] in ("vn", "vt", "vp", "o", "g", "s", "usemtl", "mtllib", "l")):
                 raise ValueError("Unsupported OBJ file")
     verts = [tuple(scale * p[k] + shift[k] for k in range(3)) for p in verts]
-    return [Triangle(verts[f[0] - 1], verts[f[1] - 1], verts[f[2] - 1], mat) for f in faces]
+    model = HitList.default()   # obj_loader.rs:22,137: one add() per face
+    for f in faces:
+        model.add(Triangle(verts[f[0] - 1], verts[f[1] - 1], verts[f[2] - 1], mat))
+    return model
 
 
 # ------------------------------------------------------------------ camera
@@ -386,6 +455,9 @@ class Scene:
         self.skybox = file if isinstance(file, RTWImage) else RTWImage.new(file)
 
     def add_element(self, element, alias):
+        if isinstance(element, HitList):   # scene/mod.rs:164-166: added as it is, the alias is not registered
+            self.elements.append(element)
+            return
         element.id = self._vend_id(alias, "Sphere" if isinstance(element, Sphere) else "Triangle")
         self.elements.append(element)
 
@@ -495,7 +567,7 @@ class Scene:
             materials.append(rec)
             return mat_ids[id(m)]
 
-        for e in self.elements:
+        def emit(e, extra_flags=0):
             ks = e.timeline.keyframes()
             v = (C.c_double * 9)()
             if isinstance(e, Sphere):
@@ -504,9 +576,20 @@ class Scene:
             else:
                 v[0:9] = [*e.a, *e.b, *e.c]
                 kind = A.CR_PRIM_TRIANGLE
-            prims.append(A.CrPrimitive(kind, material_id(e.mat), A.CR_PRIM_HIDDEN if e.hide else 0, len(keys),
-                                       len(ks), 0, v))
+            prims.append(A.CrPrimitive(kind, material_id(e.mat), (A.CR_PRIM_HIDDEN if e.hide else 0) | extra_flags,
+                                       len(keys), len(ks), 0, v))
             keys.extend(ks)
+
+        for e in self.elements:
+            if isinstance(e, HitList):   # the list record, then its objects (include/crucible_hip.h CR_PRIM_LIST)
+                objs, empty_box = e.spliced()
+                v = (C.c_double * 9)()
+                v[0:2] = [len(prims) + 1, len(objs)]
+                prims.append(A.CrPrimitive(A.CR_PRIM_LIST, 0, A.CR_LIST_EMPTY_BOX if empty_box else 0, 0, 0, 0, v))
+                for o in objs:
+                    emit(o, A.CR_PRIM_MEMBER)
+            else:
+                emit(e)
         sky_kind, sky_image = A.CR_SKY_DEFAULT, -1
         if self.skybox is not None:
             sky_kind, sky_image = A.CR_SKY_SPHERICAL, image_id(self.skybox)

@@ -58,9 +58,14 @@ enum {
 /* ---- scalar type the path computes in ---- */
 enum { CR_REAL_F32 = 0, CR_REAL_F64 = 1 };
 
-/* ---- primitives: Hittables::{Sphere,Triangle} (src/objects/mod.rs:109-115) ---- */
-enum { CR_PRIM_SPHERE = 0, CR_PRIM_TRIANGLE = 1 };
-enum { CR_PRIM_HIDDEN = 1 };   /* Sphere.hide / Triangle.hide (sphere.rs:18, triangle.rs:11) */
+/* ---- scene elements: Hittables::{Sphere,Triangle,HitList} (src/objects/mod.rs:109-115) ---- */
+enum { CR_PRIM_SPHERE = 0, CR_PRIM_TRIANGLE = 1, CR_PRIM_LIST = 2 };
+enum {
+    CR_PRIM_HIDDEN = 1,      /* Sphere.hide / Triangle.hide (sphere.rs:18, triangle.rs:11)                       */
+    CR_PRIM_MEMBER = 2,      /* this sphere/triangle is an object of a CR_PRIM_LIST record, not a scene element  */
+    CR_LIST_EMPTY_BOX = 4    /* list built by HitList::new(vec): its box stays Aabb::default() (hitlist.rs:13-18);
+                                without the flag the box is what HitList::add accumulates (hitlist.rs:24-27)     */
+};
 
 /*
  * One element of the flat scene list (Scene.elements, src/scene/mod.rs:77), in
@@ -68,6 +73,17 @@ enum { CR_PRIM_HIDDEN = 1 };   /* Sphere.hide / Triangle.hide (sphere.rs:18, tri
  * (src/objects/bvhwrapper.rs:66-67).
  *   sphere   : v[0..2] = centre, v[3] = radius          (sphere.rs:26)
  *   triangle : v[0..2] = a, v[3..5] = b, v[6..8] = c    (triangle.rs:24)
+ *   list     : a HitList handed to Scene::add_element (scene/mod.rs:164-166): v[0] = index of its first object
+ *              in prims, v[1] = number of objects (whole numbers).  The objects are consecutive spheres/triangles
+ *              flagged CR_PRIM_MEMBER, in the list's order; each belongs to exactly one list.  The BVH build
+ *              treats the list as ONE object (bvhwrapper.rs:18-22 keeps it whatever it holds): a leaf wrapper
+ *              that holds it walks every object in order with the shrinking interval and no box test
+ *              (HitList::hit, hitlist.rs:51-65); hidden objects return no hit (sphere.rs:62, triangle.rs:87)
+ *              but still count towards an add()-built box.  A list inside a list behaves exactly like its
+ *              objects spliced in place (the inner box is never read), which is how the host mirrors pass it;
+ *              a BVHWrapper as a scene element is not representable (CR_ERR_UNSUPPORTED at the mirrors).
+ *              Under the opt-in CR_BVH_SAH / _ORDERED / LBVH trees a list's visible objects are ordinary
+ *              primitives of the tree.  material, key_first, key_count are unused for a list.
  * key_first/key_count select this primitive's keyframes in CrSceneDesc.keys
  * (0 keys = static; the initial transform is the v[] values themselves).
  */

@@ -551,6 +551,7 @@ typedef struct Hittable {
     int kind;
     int mat;
     int hide;
+    int member;              /* an object of a HitList element, not a scene element itself (CR_PRIM_MEMBER) */
     Timeline tl;             /* sphere: centre+radius; triangle: vertex a (b, c below) */
     real vb[3], vc[3];
     Aabb bbox;
@@ -695,6 +696,8 @@ static void dead_update_bb(const Hittable* h, real t) {
         timeline_eval(&h->tl, t, 0, pa); timeline_eval(&tlb, t, 0, pb); timeline_eval(&tlc, t, 0, pc);
         Aabb b = triangle_bbox(v3(pa[0], pa[1], pa[2]), v3(pb[0], pb[1], pb[2]), v3(pc[0], pc[1], pc[2]));
         g_dead_box[0] = b.x.min; g_dead_box[1] = b.x.max; g_dead_box[2] = b.y.min; g_dead_box[3] = b.y.max; g_dead_box[4] = b.z.min; g_dead_box[5] = b.z.max;
+    } else if (h->kind == H_HITLIST) {   /* HitList::update_bb, hitlist.rs:33-42: every object's update, then their union (never read) */
+        for (int i = 0; i < h->n_objs; i++) dead_update_bb(h->objs[i], t);
     }
 }
 
@@ -723,9 +726,10 @@ static int bvh_hit(Hittable* b, const Ray* r, Interval ray_t, HitRecord* rec, Co
     }
     int hit_left = hittable_hit(first, r, ray_t, &hl, cn);
     Interval right_t = {ray_t.min, hit_left ? hl.t : ray_t.max};
-    /* a span-1 wrapper holds the same object twice; the reference tests it twice */
-    if (b->left == b->right && b->left->kind != H_BVH && b->left->kind != H_HITLIST) cn->prim_tests_dedup--;
+    /* a span-1 wrapper holds the same object twice; the reference tests it twice (a list: all its objects twice) */
+    const uint64_t dedup_before = cn->prim_tests_dedup;
     int hit_right = hittable_hit(second, r, right_t, &hr, cn);
+    if (b->left == b->right && b->left->kind != H_BVH) cn->prim_tests_dedup = dedup_before;
     if (hit_right) { *rec = hr; return 1; }
     if (hit_left) { *rec = hl; return 1; }
     return 0;
@@ -733,6 +737,8 @@ static int bvh_hit(Hittable* b, const Ray* r, Interval ray_t, HitRecord* rec, Co
 
 static int hittable_hit(Hittable* h, const Ray* r, Interval ray_t, HitRecord* rec, Counters* cn) {   /* objects/mod.rs:118-125 */
     int hit;
+    /* a hidden object of a list answers None before anything is computed (sphere.rs:62, triangle.rs:87); not counted as a test */
+    if (h->hide && (h->kind == H_SPHERE || h->kind == H_TRIANGLE)) return 0;
     switch (h->kind) {
         case H_SPHERE: cn->prim_tests++; cn->prim_tests_dedup++; hit = sphere_hit(h, r, ray_t, rec); break;
         case H_HITLIST: return hitlist_hit(h, r, ray_t, rec, cn);
@@ -800,7 +806,9 @@ static void scene_build_world(Scene* sc) {
     int n_vis = 0;
     Hittable** vis = (Hittable**)malloc(sizeof(Hittable*) * (size_t)(sc->n_prims + 1));
     Hittable** tmp = (Hittable**)malloc(sizeof(Hittable*) * (size_t)(sc->n_prims + 1));
-    for (int i = 0; i < sc->n_prims; i++) if (!sc->prims[i].hide) vis[n_vis++] = &sc->prims[i];
+    /* bvhwrapper.rs:16-26: hidden spheres and triangles are dropped, a HitList stays whatever it holds */
+    for (int i = 0; i < sc->n_prims; i++)
+        if (!sc->prims[i].member && (sc->prims[i].kind == H_HITLIST || !sc->prims[i].hide)) vis[n_vis++] = &sc->prims[i];
     if (n_vis == 0) {
         memset(&sc->empty_list, 0, sizeof sc->empty_list);
         sc->empty_list.kind = H_HITLIST;
@@ -1044,6 +1052,7 @@ EXPORT int32_t oracle_real_type(void) { return ORACLE_REAL_TYPE; }
 EXPORT void oracle_scene_destroy(Scene* sc) {
     if (!sc) return;
     for (int i = 0; i < sc->n_images; i++) free(sc->images[i].rgb);
+    for (int i = 0; i < sc->n_prims; i++) if (sc->prims[i].kind == H_HITLIST) free(sc->prims[i].objs);
     free(sc->images); free(sc->prims); free(sc->materials); free(sc->textures); free(sc->keys); free(sc->pool); free(sc->mat_rc);
     free(sc->empty_list.objs);
     free(sc);
@@ -1094,6 +1103,8 @@ EXPORT Scene* oracle_scene_create(const CrSceneDesc* d) {
         const CrPrimitive* p = &d->prims[i];
         Hittable* h = &sc->prims[i];
         h->mat = p->material; h->hide = (p->flags & CR_PRIM_HIDDEN) != 0;
+        h->member = (p->flags & CR_PRIM_MEMBER) != 0;
+        if (p->kind == CR_PRIM_LIST) { h->kind = H_HITLIST; h->hide = 0; continue; }   /* second pass below */
         h->tl.n_keys = p->key_count; h->tl.keys = sc->keys + p->key_first;
         if (p->kind == CR_PRIM_SPHERE) {
             h->kind = H_SPHERE;
@@ -1105,6 +1116,19 @@ EXPORT Scene* oracle_scene_create(const CrSceneDesc* d) {
             h->tl.init[3] = R(1.0);
             h->bbox = triangle_bbox(v3(h->tl.init[0], h->tl.init[1], h->tl.init[2]), v3(h->vb[0], h->vb[1], h->vb[2]),
                                     v3(h->vc[0], h->vc[1], h->vc[2]));
+        }
+    }
+    for (int i = 0; i < d->n_prims; i++) {   /* HitList elements (crucible_hip.h CR_PRIM_LIST) */
+        const CrPrimitive* p = &d->prims[i];
+        if (p->kind != CR_PRIM_LIST) continue;
+        Hittable* h = &sc->prims[i];
+        const int first = (int)p->v[0], count = (int)p->v[1];
+        h->objs = (Hittable**)malloc(sizeof(Hittable*) * (size_t)(count + 1));
+        h->n_objs = count;
+        h->bbox = aabb_empty();   /* HitList::new: Aabb::default(), hitlist.rs:13-18 */
+        for (int k = 0; k < count; k++) {
+            h->objs[k] = &sc->prims[first + k];
+            if (!(p->flags & CR_LIST_EMPTY_BOX)) h->bbox = aabb_from_boxes(h->bbox, h->objs[k]->bbox);   /* HitList::add, hitlist.rs:24-27 */
         }
     }
     scene_build_world(sc);
@@ -1152,6 +1176,11 @@ static int refit_sample(const Hittable* h, real ta, real tb, int i, real* t, int
     return ta < k->t1 && k->t1 < tb;
 }
 static Aabb prim_box_over(const Hittable* h, real ta, real tb) {
+    if (h->kind == H_HITLIST) {   /* the visible objects' boxes, united in the list's order */
+        Aabb l = aabb_empty();
+        for (int i = 0; i < h->n_objs; i++) if (!h->objs[i]->hide) l = aabb_from_boxes(l, prim_box_over(h->objs[i], ta, tb));
+        return l;
+    }
     Aabb b = prim_box_at(h, ta, 0);
     if (h->tl.n_keys == 0) return b;
     int scaled = 0;
@@ -1462,7 +1491,8 @@ EXPORT void oracle_use_list(Scene* sc) {
     memset(l, 0, sizeof *l);
     l->kind = H_HITLIST;
     l->objs = (Hittable**)malloc(sizeof(Hittable*) * (size_t)(sc->n_prims + 1));
-    for (int i = 0; i < sc->n_prims; i++) if (!sc->prims[i].hide) l->objs[l->n_objs++] = &sc->prims[i];
+    for (int i = 0; i < sc->n_prims; i++)   /* a list element's objects are in prims themselves */
+        if (sc->prims[i].kind != H_HITLIST && !sc->prims[i].hide) l->objs[l->n_objs++] = &sc->prims[i];
     sc->world = l;
 }
 

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from crucible_amd import _abi as A
-from crucible_amd.demo_builder import book1_end_scene, checkered_spheres, load_teapot, scaled_teapot
+from crucible_amd.demo_builder import book1_end_scene, checkered_spheres, load_teapot, scaled_teapot, teapot_as_list
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "crucible_amd", "host", "crucible_render")
@@ -32,7 +32,8 @@ def py_dump(sc):
 
 
 @pytest.mark.parametrize("world,build", [(1, lambda: book1_end_scene(1, scene_seed=7)), (2, lambda: checkered_spheres(1)),
-                                         (3, lambda: load_teapot(1)), (6, lambda: scaled_teapot(1))])
+                                         (3, lambda: load_teapot(1)), (6, lambda: scaled_teapot(1)),
+                                         (7, lambda: teapot_as_list(1))])
 def test_cpp_and_python_mirrors_flatten_identically(cli, tmp_path, world, build):
     out = str(tmp_path / "d.bin")
     subprocess.check_call([cli, "--world", str(world), "--scene-seed", "7", "--dump-desc", out], cwd=ROOT, stderr=subprocess.DEVNULL)

@@ -1,14 +1,14 @@
 """Seeded random scenes through the whole path: every feature the ABI carries, mixed at random -- spheres and
 triangles, all three materials, solid / nested checker / image textures, default or spherical sky, hidden primitives,
 translate / radius / ScaleX-Y-Z keys (LERP and NERP) on primitives and camera, defocus on or off, odd image sizes,
-shallow and deep paths -- rendered by the HIP library and by the oracle: bit-equal images and equal work counters, f64
+shallow and deep paths, HitList elements (seeds from 100) -- rendered by the HIP library and by the oracle: bit-equal images and equal work counters, f64
 and f32, with the reference's tree and (every third scene) with refit or an exported opt-in tree."""
 import numpy as np
 import pytest
 
 from crucible_amd import _abi as A
-from crucible_amd.scene import (LERP, LOCAL, NERP, WORLD, CheckerTexture, Dielectric, ImageTexture, Lambertian, Metal, RTWImage,
-                                Scene, SolidColor, Sphere, Triangle)
+from crucible_amd.scene import (LERP, LOCAL, NERP, WORLD, CheckerTexture, Dielectric, HitList, ImageTexture, Lambertian, Metal,
+                                RTWImage, Scene, SolidColor, Sphere, Triangle)
 
 pytestmark = pytest.mark.gpu
 
@@ -16,7 +16,7 @@ COUNTERS = ("segments", "node_tests", "prim_tests", "texel_fetches")
 REALS = [(A.CR_REAL_F64, "f64"), (A.CR_REAL_F32, "f32")]
 
 
-def random_scene(seed):
+def random_scene(seed, lists=False):
     rs = np.random.RandomState(seed)
     u = rs.uniform
     width = int(rs.choice([17, 32, 45, 64, 73]))
@@ -92,6 +92,39 @@ def random_scene(seed):
                             sc.scale_all_uniform(u(0.3, 1.8), key, interp, alias)
                 except ValueError:
                     pass   # "Missing transform data": a key earlier than an existing one of its kind, as in the reference
+    if lists:   # HitList elements (tests/test_gpu_lists.py): grown by add(), from new(vec), nested; hidden and keyed objects
+        for li in range(int(rs.randint(1, 5))):
+            objs = []
+            for k in range(int(rs.randint(0, 7))):
+                if rs.rand() < 0.6:
+                    o = Sphere.new((u(-4, 4), u(0.2, 2.0), u(-4, 3)), u(0.15, 0.9), material())
+                else:
+                    c = np.array([u(-4, 4), u(0.0, 2.0), u(-4, 3)])
+                    o = Triangle.new(*(tuple(c + u(-1.2, 1.2, 3)) for _ in range(3)), material())
+                o.hide = rs.rand() < 0.15
+                if rs.rand() < 0.4:   # objects of a list have no alias: their timelines are filled directly
+                    key, interp = float(rs.choice([0.02, 0.5, 1.0, 1.7])), (LERP if rs.rand() < 0.6 else NERP)
+                    if rs.rand() < 0.5:
+                        o.timeline.translate_point(tuple(u(-1.5, 1.5, 3)), key, interp, LOCAL)
+                    elif isinstance(o, Sphere):
+                        o.timeline.scale_sphere(u(0.1, 1.2), key, interp)
+                    else:
+                        o.timeline.scale_point(tuple(u(0.3, 1.8, 3)), key, interp)
+                objs.append(o)
+            how = rs.randint(0, 3)
+            if how == 0:
+                l = HitList.new(objs)
+            else:
+                l = HitList.default()
+                cut = len(objs) // 2 if how == 2 else len(objs)
+                for o in objs[:cut]:
+                    l.add(o)
+                if how == 2:
+                    inner = HitList.default()
+                    for o in objs[cut:]:
+                        inner.add(o)
+                    l.add(inner)
+            sc.add_element(l, f"list{li}")
     if rs.rand() < 0.5:
         sc.load_spherical_skybox(RTWImage(rs.randint(40, 256, size=(8, 16, 3)).astype(np.uint8)))
     if rs.rand() < 0.4:
@@ -102,9 +135,9 @@ def random_scene(seed):
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
-@pytest.mark.parametrize("seed", range(36))
+@pytest.mark.parametrize("seed", list(range(36)) + list(range(100, 124)))
 def test_random_scene_bit_exact(renderer, oracles, rt, tag, seed):
-    sc = random_scene(1000 + seed)
+    sc = random_scene(1000 + seed, lists=seed >= 100)   # seeds from 100: with HitList elements
     variant = seed % 3
     if variant == 1:
         sc.scene_cam.refit_boxes = True

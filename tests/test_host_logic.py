@@ -9,8 +9,8 @@ import pytest
 import scenes
 from crucible_amd import _abi as A
 from crucible_amd.demo_builder import SceneRng, book1_end_scene, load_teapot, procedural_sky
-from crucible_amd.scene import (LERP, LOCAL, NERP, WORLD, Camera, CheckerTexture, Lambertian, Metal, Scene, Sphere,
-                                load_obj)
+from crucible_amd.scene import (LERP, LOCAL, NERP, WORLD, Camera, CheckerTexture, HitList, Lambertian, Metal, Scene,
+                                Sphere, Triangle, load_obj)
 from crucible_amd.timeline import TransformTimeline
 
 
@@ -303,3 +303,25 @@ def test_mp4_command_is_the_references_ffmpeg_call():
     assert sc.mp4_command("out", 3) == ["ffmpeg", "-framerate", "24", "-i", "out/artifacts/image%03d.ppm", "-vf",
                                         "scale=trunc(iw/2)*2:trunc(ih/2)*2", "-c:v", "libx264", "-pix_fmt", "yuv420p",
                                         "-crf", "25", "out/movie.mp4"]
+
+
+def test_mirror_rejects_boxes_it_cannot_describe():
+    """HitList as a scene element (hitlist.rs:13-27): the descriptor can say "empty box" or "union of the objects";
+    add() after new(vec), clear() after add() and an add()ed inner list with an empty box are neither."""
+    m = Lambertian.new_from_color((0.5, 0.5, 0.5), 1.0)
+    mixed = HitList.new([Sphere.new((0, 0, 0), 1.0, m)])
+    mixed.add(Sphere.new((2, 0, 0), 1.0, m))
+    with pytest.raises(ValueError):
+        mixed.spliced()
+    cleared = HitList.default()
+    cleared.add(Sphere.new((0, 0, 0), 1.0, m))
+    cleared.clear()
+    with pytest.raises(ValueError):
+        cleared.spliced()
+    outer = HitList.default()
+    outer.add(HitList.new([Sphere.new((0, 0, 0), 1.0, m)]))   # the inner box is empty, the spliced union is not
+    with pytest.raises(ValueError):
+        outer.spliced()
+    fine = HitList.new([HitList.new([Triangle.new((0, 0, 0), (1, 0, 0), (0, 1, 0), m)]), Sphere.new((0, 0, 0), 1.0, m)])
+    objs, empty = fine.spliced()
+    assert empty and [type(o).__name__ for o in objs] == ["Triangle", "Sphere"]
