@@ -60,6 +60,7 @@ template <typename real> struct DevScene {
     size_t lds_bytes = 0;
     bool animated = false;
     bool has_triangles = false;
+    bool has_leaf_runs = false;              // some leaf names its primitives through leaf_runs (a HitList element)
     DevBuf entries_refit;                    // working copy whose boxes refit_level_kernel rewrites per frame
     bool ordered = false;                    // CR_BVH_SAH_ORDERED: `entries` holds EntryO records
     size_t entry_bytes = sizeof(Entry<real>);
@@ -717,6 +718,7 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
     } else
     HIP_TRY(h, up(ds.entries, up_entries.data(), up_entries.size() * sizeof(Entry<real>), entry_pad<Entry<real>>()));
     HIP_TRY(h, up(ds.leaf_runs, leaf_runs.data(), leaf_runs.size() * sizeof(int32_t)));
+    ds.has_leaf_runs = !leaf_runs.empty();
     HIP_TRY(h, up(ds.prims, leaf_prims.data(), leaf_prims.size() * sizeof(Prim<real>)));
     HIP_TRY(h, up(ds.mats, mats.data(), mats.size() * sizeof(Mat<real>)));
     HIP_TRY(h, up(ds.texs, texs.data(), texs.size() * sizeof(Tex<real>)));
@@ -1083,7 +1085,7 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     }
     KernelArgs<real> a;
     memset(&a, 0, sizeof a);
-    a.entries = (const Entry<real>*)ds.entries.p; a.prims = (const Prim<real>*)ds.prims.p; a.leaf_runs = (const int32_t*)ds.leaf_runs.p;
+    a.entries = (const Entry<real>*)ds.entries.p; a.prims = (const Prim<real>*)ds.prims.p; a.leaf_runs = ds.has_leaf_runs ? (const int32_t*)ds.leaf_runs.p : nullptr;
     const bool refit = p->refit_boxes && ds.animated && ds.n_entries > 0;   // without primitive keys the boxes would not change
     a.mats = (const Mat<real>*)ds.mats.p; a.texs = (const Tex<real>*)ds.texs.p;
     a.images = (const ImageRef*)h->images.p; a.texels = (const uint32_t*)h->texels.p;
@@ -1159,7 +1161,8 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     a.walk_round_steps = (uint32_t)(h->walk_round_steps >= 0 ? h->walk_round_steps : (ds.has_triangles ? 8 : 10));
     a.sg_on = 0; a.sg_lw = a.sg_lh = 3; a.sg_groups = 0; a.sg_total = 0; a.sample_buf = nullptr;   // set by launch()
 
-    const bool anim = ds.animated || c.animated;
+    // the ANIM kernels also carry the decode of leaves that hold a HitList element (pathtrace.hpp walk_round)
+    const bool anim = ds.animated || c.animated || ds.has_leaf_runs;
     if (ds.ordered) {   // near-child-first walk: megakernel only
         if (h->pipeline != 0) return fail(h, CR_ERR_UNSUPPORTED, "CR_BVH_SAH_ORDERED is implemented by the megakernel pipeline only");
         if (ds.n_entries > 0 && ds.lds_bytes <= h->lds_limit) {

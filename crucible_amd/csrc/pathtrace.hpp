@@ -908,10 +908,8 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
     }
     if (leaf >= 0) {
         CR_DIAG_HIT(dg, DG_LEAFPH_WAVE, DG_LEAFPH_LANE);
-        int32_t first = leaf >> 1, count = (leaf & 1) + 1;
-        if (leaf & kLeafRun) { first = A.leaf_runs[2 * (leaf & ~kLeafRun)]; count = A.leaf_runs[2 * (leaf & ~kLeafRun) + 1]; }
-        for (int32_t k = 0; k < count; k++) {
-            const Prim<real>& p = prims[first + k];
+        auto test = [&](int32_t pi) {
+            const Prim<real>& p = prims[pi];
             c_prim++;
             CR_DIAG_HIT(dg, DG_PRIM_WAVE, DG_PRIM_LANE);
             real t;
@@ -929,7 +927,16 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
                 }
                 h = triangle_t(a, b, c, ro, rd, tmin, w.best_t, t);
             }
-            if (h) { w.best_t = t; w.best = first + k; }
+            if (h) { w.best_t = t; w.best = pi; }
+        };
+        // Scenes with a HitList element run the ANIM kernels (capi.hip), so the static kernels -- the headline's -- keep
+        // the one-or-two-record loop alone; A.leaf_runs is null unless such an element exists (a scalar test)
+        if (!ANIM || A.leaf_runs == nullptr || !(leaf & kLeafRun)) {
+            const int32_t first = leaf >> 1, count = (leaf & 1) + 1;
+            for (int32_t k = 0; k < count; k++) test(first + k);
+        } else {
+            const int32_t first = A.leaf_runs[2 * (leaf & ~kLeafRun)], count = A.leaf_runs[2 * (leaf & ~kLeafRun) + 1];
+            for (int32_t k = 0; k < count; k++) test(first + k);
         }
     }
 }
