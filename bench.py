@@ -63,6 +63,19 @@ def algorithmic_bytes(st, width, height, entry_bytes=32, prim_bytes=16):
             st["texel_fetches"] * 4 + width * height * 12)
 
 
+def hbm_probe():
+    """What scripts/calib/hbm_peak.hip sustained on an MI355X of this pool (read / write / copy / triad over 2 GiB
+    arrays), kept under profiles/: the measured figure SURVEY 8(d) asks for beside the nominal 8 TB/s."""
+    path = os.path.join(ROOT, "profiles", "r02_hbm_peak.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return {k: d[k] for k in ("read_GBps", "write_GBps", "copy_GBps", "triad_GBps", "measured_peak_GBps") if k in d} | {
+        "source": "profiles/r02_hbm_peak.json (scripts/calib/hbm_peak.hip, a separate run -- not measured in this one)"}
+
+
 def host_cores():
     """Cores this process may use: the affinity mask and the cgroup CPU quota, not the machine's logical CPU count."""
     n = os.cpu_count() or 1
@@ -359,7 +372,8 @@ def main():
                          "hbm": {"algorithmic_bytes_per_launch": int(B), "achieved_algorithmic_GBps": round(B / (k_ms * 1e-3) / 1e9, 2) if k_ms > 0 else None,
                                  "peak_GBps": HBM_PEAK_GBS, "note": "SURVEY 8(d) byte model; exceeds the HBM peak because the scene is served from LDS -- "
                                                                    "not a bound of this kernel",
-                                 "measured_GBps_from_profile": round(traffic / (k_ms * 1e-3) / 1e9, 1) if traffic and k_ms > 0 else None},
+                                 "measured_GBps_from_profile": round(traffic / (k_ms * 1e-3) / 1e9, 1) if traffic and k_ms > 0 else None,
+                                 "probed_peak": hbm_probe()},
                          "executed": pmc},
             "kernel_msamples_per_s": round(W * H * s_count / (k_ms * 1e-3) / 1e6, 2) if k_ms > 0 else None,
         }
