@@ -749,13 +749,13 @@ template <typename real> void key_to_real(const CrKeyframe& k, Key<real>& o) {
     o.t0 = (real)k.t0; o.t1 = (real)k.t1; o.a = (real)k.a; o.b = (real)k.b; o.channel = k.channel; o.interp = k.interp;
 }
 
-template <typename real, int RES, bool ANIM, bool ORD = false, bool LATENCY = false>
+template <typename real, int RES, bool ANIM, bool ORD = false, bool LATENCY = false, bool CAMK = false>
 int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, CrStats* stats) {
     constexpr bool LDS = RES != RES_GLOBAL;
     static_assert(!LATENCY || RES == RES_TOP, "the 6-waves-per-SIMD entry point exists for RES_TOP only");
     KernelArgs<real> args = args_in;
-    void (*kern)(const KernelArgs<real>) = pathtrace_kernel<real, RES, ANIM, ORD>;
-    if (LATENCY) kern = pathtrace_kernel_latency<real, ANIM, ORD>;
+    void (*kern)(const KernelArgs<real>) = pathtrace_kernel<real, RES, ANIM, ORD, CAMK>;
+    if (LATENCY) kern = pathtrace_kernel_latency<real, ANIM, ORD, CAMK>;
     const int max_block = LATENCY ? LatencyBlock : MaxBlock<real>::value;
     if (LDS) HIP_TRY(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     // Workgroup size: the candidate that keeps the most waves resident per CU (a larger
@@ -1162,12 +1162,13 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     a.sg_on = 0; a.sg_lw = a.sg_lh = 3; a.sg_groups = 0; a.sg_total = 0; a.sample_buf = nullptr;   // set by launch()
 
     // the ANIM kernels also carry the decode of leaves that hold a HitList element (pathtrace.hpp walk_round)
-    const bool anim = ds.animated || c.animated || ds.has_leaf_runs;
+    const bool anim = ds.animated || ds.has_leaf_runs;   // keyed primitives (the ANIM kernels also follow a keyed camera)
+    const bool cam_keys = c.animated;                     // camera keys alone: the static kernels' CAMK variant
     if (ds.ordered) {   // near-child-first walk: megakernel only
         if (h->pipeline != 0) return fail(h, CR_ERR_UNSUPPORTED, "CR_BVH_SAH_ORDERED is implemented by the megakernel pipeline only");
         if (ds.n_entries > 0 && ds.lds_bytes <= h->lds_limit) {
             a.lds_entries = ds.n_entries;
-            return anim ? launch<real, RES_LDS, true, true>(h, a, ds.lds_bytes, stats) : launch<real, RES_LDS, false, true>(h, a, ds.lds_bytes, stats);
+            return anim ? launch<real, RES_LDS, true, true, false>(h, a, ds.lds_bytes, stats) : (cam_keys ? launch<real, RES_LDS, false, true, false, true>(h, a, ds.lds_bytes, stats) : launch<real, RES_LDS, false, true, false>(h, a, ds.lds_bytes, stats));
         }
         constexpr bool f32 = std::is_same<real, float>::value;   // the double kernel needs far more than 80 VGPRs: it halves there
         const bool latency = f32 && h->latency_entries > 0 && ds.n_entries > h->latency_entries;
@@ -1175,29 +1176,29 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
         if (top > 0) {
             a.lds_entries = top;
             const size_t bytes = (size_t)top * sizeof(EntryO<real>);
-            if constexpr (f32) if (latency) return anim ? launch<real, RES_TOP, true, true, true>(h, a, bytes, stats) : launch<real, RES_TOP, false, true, true>(h, a, bytes, stats);
-            return anim ? launch<real, RES_TOP, true, true>(h, a, bytes, stats) : launch<real, RES_TOP, false, true>(h, a, bytes, stats);
+            if constexpr (f32) if (latency) return anim ? launch<real, RES_TOP, true, true, true>(h, a, bytes, stats) : (cam_keys ? launch<real, RES_TOP, false, true, true, true>(h, a, bytes, stats) : launch<real, RES_TOP, false, true, true>(h, a, bytes, stats));
+            return anim ? launch<real, RES_TOP, true, true, false>(h, a, bytes, stats) : (cam_keys ? launch<real, RES_TOP, false, true, false, true>(h, a, bytes, stats) : launch<real, RES_TOP, false, true, false>(h, a, bytes, stats));
         }
         a.lds_entries = 0;
-        return anim ? launch<real, RES_GLOBAL, true, true>(h, a, 0, stats) : launch<real, RES_GLOBAL, false, true>(h, a, 0, stats);
+        return anim ? launch<real, RES_GLOBAL, true, true, false>(h, a, 0, stats) : (cam_keys ? launch<real, RES_GLOBAL, false, true, false, true>(h, a, 0, stats) : launch<real, RES_GLOBAL, false, true, false>(h, a, 0, stats));
     }
-    if (h->pipeline == 1) return render_wavefront<real>(h, a, ds, anim, stats);
+    if (h->pipeline == 1) return render_wavefront<real>(h, a, ds, anim || cam_keys, stats);
     if (h->pipeline == 2) {   // LDS-queue megakernel when scene + slot arrays fit in LDS, else the plain megakernel below
         const size_t budget = 160 * 1024, state = queue_state_bytes<real>();
         if (ds.n_entries > 0 && ds.lds_bytes + 16 + state <= budget) {
             a.lds_entries = ds.n_entries;
-            return anim ? launch_queue<real, RES_LDS, true>(h, a, ds.lds_bytes, stats) : launch_queue<real, RES_LDS, false>(h, a, ds.lds_bytes, stats);
+            return (anim || cam_keys) ? launch_queue<real, RES_LDS, true>(h, a, ds.lds_bytes, stats) : launch_queue<real, RES_LDS, false>(h, a, ds.lds_bytes, stats);
         }
         if (ds.n_entries > 0 && state + 16 * 1024 <= budget) {
             const size_t top_bytes = std::min(h->lds_top_bytes, (budget - state - 64) & ~(size_t)1023);
             a.lds_entries = (int32_t)std::min<size_t>((size_t)ds.n_entries, top_bytes / sizeof(Entry<real>));
             const size_t bytes = (size_t)a.lds_entries * sizeof(Entry<real>);
-            return anim ? launch_queue<real, RES_TOP, true>(h, a, bytes, stats) : launch_queue<real, RES_TOP, false>(h, a, bytes, stats);
+            return (anim || cam_keys) ? launch_queue<real, RES_TOP, true>(h, a, bytes, stats) : launch_queue<real, RES_TOP, false>(h, a, bytes, stats);
         }
     }
     if (ds.n_entries > 0 && ds.lds_bytes <= h->lds_limit) {
         a.lds_entries = ds.n_entries;
-        return anim ? launch<real, RES_LDS, true>(h, a, ds.lds_bytes, stats) : launch<real, RES_LDS, false>(h, a, ds.lds_bytes, stats);
+        return anim ? launch<real, RES_LDS, true, false, false>(h, a, ds.lds_bytes, stats) : (cam_keys ? launch<real, RES_LDS, false, false, false, true>(h, a, ds.lds_bytes, stats) : launch<real, RES_LDS, false, false, false>(h, a, ds.lds_bytes, stats));
     }
     constexpr bool f32 = std::is_same<real, float>::value;   // the double kernel needs far more than 80 VGPRs: it halves there
     const bool latency = f32 && h->latency_entries > 0 && ds.n_entries > h->latency_entries;
@@ -1208,11 +1209,11 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
         // materials and textures ride along when they are small (the tree can be large with two materials)
         const size_t side = (((size_t)ds.n_mats * sizeof(Mat<real>) + 15) & ~(size_t)15) + (((size_t)ds.n_texs * sizeof(Tex<real>) + 15) & ~(size_t)15);
         if (side <= h->lds_side_limit) { a.lds_side = 1; bytes = ((bytes + 15) & ~(size_t)15) + side; }
-        if constexpr (f32) if (latency) return anim ? launch<real, RES_TOP, true, false, true>(h, a, bytes, stats) : launch<real, RES_TOP, false, false, true>(h, a, bytes, stats);
-        return anim ? launch<real, RES_TOP, true>(h, a, bytes, stats) : launch<real, RES_TOP, false>(h, a, bytes, stats);
+        if constexpr (f32) if (latency) return anim ? launch<real, RES_TOP, true, false, true>(h, a, bytes, stats) : (cam_keys ? launch<real, RES_TOP, false, false, true, true>(h, a, bytes, stats) : launch<real, RES_TOP, false, false, true>(h, a, bytes, stats));
+        return anim ? launch<real, RES_TOP, true, false, false>(h, a, bytes, stats) : (cam_keys ? launch<real, RES_TOP, false, false, false, true>(h, a, bytes, stats) : launch<real, RES_TOP, false, false, false>(h, a, bytes, stats));
     }
     a.lds_entries = 0;
-    return anim ? launch<real, RES_GLOBAL, true>(h, a, 0, stats) : launch<real, RES_GLOBAL, false>(h, a, 0, stats);
+    return anim ? launch<real, RES_GLOBAL, true, false, false>(h, a, 0, stats) : (cam_keys ? launch<real, RES_GLOBAL, false, false, false, true>(h, a, 0, stats) : launch<real, RES_GLOBAL, false, false, false>(h, a, 0, stats));
 }
 
 int32_t validate_render(CrHandle* h, const CrCameraDesc* cam, const CrRenderParams* p) {

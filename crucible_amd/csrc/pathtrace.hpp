@@ -631,7 +631,11 @@ template <typename real> CR_D void random_in_unit_disk_dev(uint64_t& s, real& px
 
 // Camera::cast_ray's per-sample ray (ray_casting.rs:82-105): seeds the sample's RNG stream and draws
 // time, pixel offset and (with defocus) the lens point, in the reference's order.
-template <typename real, bool ANIM>
+// ANIM: the kernels for keyed primitives, which also follow a keyed camera (cam.animated, per launch).  CAMK: the
+// static-primitive kernels with the camera keys compiled in -- a movie that only moves the camera keeps the static walk
+// (the teapot orbit frame: +6.5 % in f64 over running it on the ANIM kernels; folding the camera code into the plain
+// static kernels instead cost book1 0.9 % f64 / 1.8 % f32, so it is a variant of its own).
+template <typename real, bool ANIM, bool CAMK = false>
 CR_D void camera_ray(const KernelArgs<real>& A, uint32_t pix_i, uint32_t pix_j, int32_t sample, uint64_t& rng, V3<real>& ro, V3<real>& rd,
                      real& rtime) {
     const CamConst<real>& cam = A.cam;
@@ -641,7 +645,7 @@ CR_D void camera_ray(const KernelArgs<real>& A, uint32_t pix_i, uint32_t pix_j, 
     real ox = rng_uniform<real>(rng) - real(0.5);   // sample_square, camera/mod.rs:368-376
     real oy = rng_uniform<real>(rng) - real(0.5);
     CamFrame<real> f;
-    if (ANIM && cam.animated) {
+    if ((ANIM || CAMK) && cam.animated) {
         real fx = cam.from.x, fy = cam.from.y, fz = cam.from.z, fw = real(1);
         real ax = cam.at.x, ay = cam.at.y, az = cam.at.z, aw = real(1);
         timeline_eval(A.cam_keys + cam.from_key_first, cam.from_key_count, ts, fx, fy, fz, fw);
@@ -1019,7 +1023,7 @@ template <typename real> struct MaxBlock { static constexpr int value = 1024; };
 // One lane = one pixel at a time, all of that pixel's samples in draw order (so the
 // per-pixel sum is the reference's sequential sum).  Lanes that finish a pixel pull the
 // next pixel index with one wave-aggregated atomic (ballot + prefix count).
-template <typename real, int RES, bool ANIM, bool ORD>
+template <typename real, int RES, bool ANIM, bool ORD, bool CAMK = false>
 CR_D void pathtrace_body(const KernelArgs<real>& A) {
     using EntryT = typename EntryOf<real, ORD>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1145,7 +1149,7 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
         // ---------------- regeneration: camera rays (cast_ray, ray_casting.rs:82-105)
         if (state == ST_NEED_SAMPLE) {
             CR_DIAG_HIT(dgp, DG_REGEN_WAVE, DG_REGEN_LANE);
-            camera_ray<real, ANIM>(A, pix_i, pix_j, sample, rng, ro, rd, rtime);
+            camera_ray<real, ANIM, CAMK>(A, pix_i, pix_j, sample, rng, ro, rd, rtime);
             depth_left = A.max_depth; stack_n = 0;
             state = ST_TRACE;
         }
@@ -1229,9 +1233,9 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
 
     }
 }
-template <typename real, int RES, bool ANIM, bool ORD = false>
+template <typename real, int RES, bool ANIM, bool ORD = false, bool CAMK = false>
 __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const KernelArgs<real> A) {
-    pathtrace_body<real, RES, ANIM, ORD>(A);
+    pathtrace_body<real, RES, ANIM, ORD, CAMK>(A);
 }
 
 // The same kernel compiled for 6 waves per SIMD (<= 80 VGPRs, 512-thread groups), for trees far larger than the
@@ -1239,10 +1243,10 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
 // extra spills cost (1M spheres +11 %; the LDS-resident book1 and the 8K-wrapper teapot lose 3 % and stay on
 // pathtrace_kernel).  RES_TOP only.
 constexpr int LatencyBlock = 512;
-template <typename real, bool ANIM, bool ORD = false>
+template <typename real, bool ANIM, bool ORD = false, bool CAMK = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(64, LatencyBlock), amdgpu_waves_per_eu(6, 6)))
 pathtrace_kernel_latency(const KernelArgs<real> A) {
-    pathtrace_body<real, RES_TOP, ANIM, ORD>(A);
+    pathtrace_body<real, RES_TOP, ANIM, ORD, CAMK>(A);
 }
 
 // average_samples' running sum (ray_casting.rs:161-165) for the sample-granular mode: the batch's colours are added
