@@ -33,7 +33,7 @@ for src, dst in (("bench.json", "r02_bench.json"), ("bench_f32.json", "r02_bench
         d["roofline"]["hbm"]["measured_GBps_from_profile"] = round(pmc[key]["hbm_bytes"] / (k_ms * 1e-3) / 1e9, 1)
     json.dump(d, open(os.path.join(P, dst), "w"))
     open(os.path.join(P, dst), "a").write("\n")
-ks = glob.glob(os.path.join(O, "kt", "**", "*kernel_stats.csv"), recursive=True)[0]
+ks = max(glob.glob(os.path.join(O, "kt", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)   # the latest run's
 shutil.copy(ks, os.path.join(P, "r02_bench_kernel_stats.csv"))
 kt = {r["Name"]: float(r["AverageNs"]) / 1e6 for r in csv.DictReader(open(ks))}
 kt_main = next(v for k, v in kt.items() if "pathtrace_kernel<double" in k)
