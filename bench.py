@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--spp", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-line", action="store_true", help="skip the short f32 timing carried as `f32_fast_mode`")
+    ap.add_argument("--no-optin-line", action="store_true", help="skip the short CR_BVH_SAH_ORDERED timing carried as `opt_in_tree`")
     ap.add_argument("--workload", choices=["book1", "teapot", "million", "movie"], default="book1",
                     help="book1 = BASELINE configs[1] (the headline); teapot/million/movie = configs[2]/[3]/[4], extra lines")
     ap.add_argument("--bvh", choices=["reference", "sah", "ordered", "lbvh"], default="reference",
@@ -321,6 +322,36 @@ def main():
                             "restatement only, ~29 % of pixels differ from the f64 image by more than 1e-4 (DESIGN.md section 2)"}
         del o32
 
+    # the opt-in tree of SURVEY 8(f) row 1 on the same frame, carried as an extra key: the same image bit for bit
+    # (checked here, on the device), fewer box tests.  The headline stays on the reference's own topology.
+    optin_line = None
+    if rank == 0 and world == 1 and args.bvh == "reference" and not args.no_optin_line and r is not None and not frame_sharded:
+        ref_img = torch.empty_like(out)
+        r.render_device(cam, ref_img.data_ptr(), seed=seed, real_type=real_type)
+        r.last_kernel_ms()
+        flat_o = scene.flatten()
+        flat_o.desc.bvh_mode = A.CR_BVH_SAH_ORDERED
+        r2 = Renderer(dev_index)
+        try:
+            r2.upload_scene(flat_o)
+            o2 = torch.empty_like(out)
+            ms2 = []
+            for _ in range(3):
+                r2.render_device(cam, o2.data_ptr(), seed=seed, real_type=real_type)
+                ms2.append(r2.last_kernel_ms())
+            st2 = r2.render_device(cam, o2.data_ptr(), seed=seed, real_type=real_type, want_stats=True)
+            best = min(ms2[1:])
+            optin_line = {"bvh": "CR_BVH_SAH_ORDERED (binned SAH, near child first)", "value": round(W * H * spp / (best * 1e-3) / 1e6, 2),
+                          "unit": "Msamples/s", "kernel_ms": round(best, 3), "dtype": args.real,
+                          "image_identical_to_reference_topology": bool(torch.equal(o2, ref_img)),
+                          "node_tests_per_segment": round(st2["node_tests"] / max(1, st2["segments"]), 2),
+                          "note": "kernel time of the best of 2 renders after 1 warm-up; the frame is compared on the device with the "
+                                  "reference-topology frame of the same seed"}
+            del o2
+        finally:
+            r2.close()
+        del ref_img
+
     if rank == 0:
         total_samples = W * H * spp * args.steps * (world if frame_sharded else 1)
         value = total_samples / elapsed / 1e6
@@ -379,6 +410,8 @@ def main():
         }
         if f32_line:
             rec["f32_fast_mode"] = f32_line
+        if optin_line:
+            rec["opt_in_tree"] = optin_line
         if world == 1 and not args.no_cpu_baseline and args.workload != "million":
             rec["cpu_baseline"] = cpu_baseline(scene, seed, 14.0, False)
             rec["cpu_baseline_faithful"] = cpu_baseline(scene, seed, 10.0, True)

@@ -5,7 +5,7 @@ R=$PWD
 O=gpurun_out/r02p
 mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/kt -- python3 $R/bench.py --steps 3 --no-cpu-baseline --no-f32-line > $R/$O/kt_bench.json 2> $R/$O/kt.err ); echo "kernel-trace rc=$?"
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/kt -- python3 $R/bench.py --steps 3 --no-cpu-baseline --no-f32-line --no-optin-line > $R/$O/kt_bench.json 2> $R/$O/kt.err ); echo "kernel-trace rc=$?"
 python bench.py --real f32 --no-cpu-baseline > $O/bench_f32.json 2>/dev/null; echo f32 done
 python bench.py --workload teapot --no-cpu-baseline --steps 2 > $O/bench_teapot.json 2>/dev/null; echo teapot done
 python bench.py --workload million --no-cpu-baseline --steps 2 > $O/bench_million.json 2>/dev/null; echo million done

@@ -157,3 +157,29 @@ def test_unknown_bvh_mode_is_rejected(renderer):
         renderer.upload_scene(sc.flatten())
     sc.bvh_mode = A.CR_BVH_REFERENCE
     renderer.upload_scene(sc.flatten())
+
+
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+@pytest.mark.parametrize("scene", ["book1", "teapot", "million", "movie"])
+def test_opt_in_trees_render_the_reference_image_on_the_baseline_scenes(renderer, rt, tag, scene):
+    """For static primitives with true boxes any tree returns the same closest hits (up to exact ties in t, which
+    random scenes do not produce): on the four BASELINE scenes -- book1, teapot + environment map, the 1M-sphere
+    field, a movie frame (keyed camera) -- CR_BVH_SAH, _ORDERED and LBVH give the reference topology's frame bit for bit.
+    bench.py repeats this check at full size (`opt_in_tree.image_identical_to_reference_topology`)."""
+    from crucible_amd.demo_builder import load_teapot, million_spheres, procedural_sky, teapot_orbit_movie
+    if scene == "book1":
+        sc = book1_end_scene(1, scene_seed=1, image_width=320, samples=8)
+    elif scene == "teapot":
+        sc = load_teapot(1, image_width=256, samples=6, sky=procedural_sky())
+    elif scene == "million":
+        sc = million_spheres(1, scene_seed=1, image_width=256, samples=4)
+    else:
+        sc = teapot_orbit_movie(1, image_width=192, samples=6)
+        sc.scene_cam.frame = 37
+    frames = []
+    for mode in (A.CR_BVH_REFERENCE, A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED, A.CR_BVH_LBVH):
+        upload(renderer, sc, mode)
+        img, _ = renderer.render(sc.scene_cam, seed=77, real_type=rt)
+        frames.append(img)
+    for f in frames[1:]:
+        assert np.array_equal(frames[0], f)
