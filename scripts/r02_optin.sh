@@ -3,7 +3,7 @@ O=gpurun_out/r02o; mkdir -p $O
 for b in sah ordered lbvh; do
   python bench.py --bvh $b --no-cpu-baseline --no-f32-line --steps 3 > $O/bench_$b.json 2>/dev/null; echo "book1 $b rc=$?"
 done
-for b in sah lbvh; do
+for b in sah ordered lbvh; do
   python bench.py --workload teapot --bvh $b --no-cpu-baseline --no-f32-line --steps 2 > $O/bench_teapot_$b.json 2>/dev/null; echo "teapot $b rc=$?"
   python bench.py --workload million --bvh $b --no-cpu-baseline --no-f32-line --steps 2 > $O/bench_million_$b.json 2>/dev/null; echo "million $b rc=$?"
 done
