@@ -61,6 +61,8 @@ template <typename real> struct DevScene {
     bool animated = false;
     bool has_triangles = false;
     bool has_leaf_runs = false;              // some leaf names its primitives through leaf_runs (a HitList element)
+    bool has_lists = false;                  // the tree was built over at least one HitList element: its construction-time box
+                                             // (empty, or grown over hidden objects too) is not what refit derives
     DevBuf entries_refit;                    // working copy whose boxes refit_level_kernel rewrites per frame
     bool ordered = false;                    // CR_BVH_SAH_ORDERED: `entries` holds EntryO records
     size_t entry_bytes = sizeof(Entry<real>);
@@ -719,6 +721,7 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
     HIP_TRY(h, up(ds.entries, up_entries.data(), up_entries.size() * sizeof(Entry<real>), entry_pad<Entry<real>>()));
     HIP_TRY(h, up(ds.leaf_runs, leaf_runs.data(), leaf_runs.size() * sizeof(int32_t)));
     ds.has_leaf_runs = !leaf_runs.empty();
+    ds.has_lists = any_lists;
     HIP_TRY(h, up(ds.prims, leaf_prims.data(), leaf_prims.size() * sizeof(Prim<real>)));
     HIP_TRY(h, up(ds.mats, mats.data(), mats.size() * sizeof(Mat<real>)));
     HIP_TRY(h, up(ds.texs, texs.data(), texs.size() * sizeof(Tex<real>)));
@@ -1086,7 +1089,8 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     KernelArgs<real> a;
     memset(&a, 0, sizeof a);
     a.entries = (const Entry<real>*)ds.entries.p; a.prims = (const Prim<real>*)ds.prims.p; a.leaf_runs = ds.has_leaf_runs ? (const int32_t*)ds.leaf_runs.p : nullptr;
-    const bool refit = p->refit_boxes && ds.animated && ds.n_entries > 0;   // without primitive keys the boxes would not change
+    // without primitive keys the boxes would not change -- unless a HitList element's box is not its objects' union
+    const bool refit = p->refit_boxes && (ds.animated || ds.has_lists) && ds.n_entries > 0;
     a.mats = (const Mat<real>*)ds.mats.p; a.texs = (const Tex<real>*)ds.texs.p;
     a.images = (const ImageRef*)h->images.p; a.texels = (const uint32_t*)h->texels.p;
     a.keys = (const Key<real>*)ds.keys.p;

@@ -1,0 +1,52 @@
+"""Seeded random scenes beyond the committed ones (tests/test_gpu_fuzz.py's generator), HIP library vs oracle: images and
+counters must be equal.  usage: fuzz_campaign.py FIRST_SEED COUNT [lists]   -- prints one line per mismatch and a summary.
+Test infrastructure (it imports the oracle); not part of the product."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch  # noqa: F401
+from crucible_amd import _abi as A
+from crucible_amd.renderer import Renderer
+from oracle.oracle import Oracle
+from test_gpu_fuzz import random_scene, COUNTERS
+
+first, count = int(sys.argv[1]), int(sys.argv[2])
+lists = len(sys.argv) > 3
+oracles = {A.CR_REAL_F64: Oracle(A.CR_REAL_F64), A.CR_REAL_F32: Oracle(A.CR_REAL_F32)}
+r = Renderer(0)
+bad, nan_scenes, t0 = 0, 0, time.time()
+for seed in range(first, first + count):
+    sc = random_scene(seed, lists=lists)
+    variant = seed % 3
+    sc.scene_cam.refit_boxes = variant == 1
+    if variant == 2:
+        sc.bvh_mode = [A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED, A.CR_BVH_LBVH][(seed // 3) % 3]
+    for rt in (A.CR_REAL_F64, A.CR_REAL_F32):
+        try:
+            r.upload_scene(sc.flatten())
+            try:
+                img, st = r.render(sc.scene_cam, seed=seed, real_type=rt)
+                gpu_nan = False
+            except Exception as e:
+                if getattr(e, "code", None) != A.CR_ERR_NAN:
+                    raise
+                gpu_nan = True
+            tree = r.export_bvh(rt) if variant == 2 else None
+            ref, rst = oracles[rt].render_image(sc, seed=seed, tree=tree)
+            if gpu_nan or rst["nan_pixels"]:
+                nan_scenes += 1
+                if gpu_nan != (rst["nan_pixels"] > 0):
+                    bad += 1; print(f"MISMATCH seed {seed} rt {rt}: NaN policy gpu={gpu_nan} oracle={rst['nan_pixels']}", flush=True)
+                continue
+            if not np.array_equal(img, ref):
+                bad += 1; print(f"MISMATCH seed {seed} rt {rt} variant {variant}: {(img != ref).any(axis=2).sum()} pixels differ", flush=True)
+            for k in COUNTERS:
+                if st[k] != rst[k]:
+                    bad += 1; print(f"MISMATCH seed {seed} rt {rt} variant {variant}: counter {k} {st[k]} vs {rst[k]}", flush=True)
+        except Exception as e:
+            bad += 1; print(f"ERROR seed {seed} rt {rt}: {type(e).__name__}: {e}", flush=True)
+    if (seed - first) % 100 == 99:
+        print(f"... {seed - first + 1} scenes, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+print(f"done: {count} scenes x 2 precisions from seed {first}{' with lists' if lists else ''}: {bad} mismatches, {nan_scenes} NaN-policy renders, {time.time() - t0:.0f} s")
+r.close()

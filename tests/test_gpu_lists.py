@@ -171,6 +171,14 @@ def test_a_list_is_its_objects_when_nothing_clips(renderer, oracles, rt, tag):
     assert not np.array_equal(imgs[0], imgs[2])
     ref, _ = oracles[rt].render_image(build("new"), seed=SEED)
     assert np.array_equal(imgs[2], ref)
+    # refit_boxes re-derives every wrapper box from what is under it, also in a scene without a single key: the
+    # empty-box list gets its objects' box and nothing is lost any more (found by scripts/fuzz_campaign.py, seed 80431:
+    # the device used to skip the refit when no primitive was keyed)
+    sc = build("new")
+    fitted, fst = render(renderer, sc, rt, refit=True)
+    ref, rst = oracles[rt].render_image(sc, seed=SEED)
+    same(fitted, fst, ref, rst)
+    assert np.array_equal(fitted, imgs[0])
 
 
 def test_descriptor_rules(renderer):
