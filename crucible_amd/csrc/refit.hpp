@@ -52,6 +52,12 @@ CR_HD void timeline_eval_side(const Key<real>* keys, int n, real t, bool before_
     if (skind) *skind = sk;
 }
 
+// A sample box with a coordinate that is not a number is not united (a zero-length LERP key evaluated exactly at its
+// own start gives 0/0): the rule would otherwise depend on the order of its unions.  Ray times are drawn from a
+// continuum, so the instant itself carries no rays.
+template <typename real> CR_HD bool box_is_number(const real blo[3], const real bhi[3]) {
+    return blo[0] == blo[0] && blo[1] == blo[1] && blo[2] == blo[2] && bhi[0] == bhi[0] && bhi[1] == bhi[1] && bhi[2] == bhi[2];
+}
 template <typename real> CR_HD void enclose(real lo[3], real hi[3], const real blo[3], const real bhi[3]) {
     for (int a = 0; a < 3; a++) {   // Interval::tight_enclose, utils.rs:629-633
         lo[a] = lo[a] <= blo[a] ? lo[a] : blo[a];
@@ -81,7 +87,7 @@ CR_HD void prim_box_at2(const Prim<real>& p, const Key<real>* keys, real t, bool
         bhi[a] = r_fmax(v[0][a], r_fmax(v[1][a], v[2][a]));
         blo[a] = r_fmin(v[0][a], r_fmin(v[1][a], v[2][a]));
     }
-    enclose(lo, hi, blo, bhi);
+    if (box_is_number(blo, bhi)) enclose(lo, hi, blo, bhi);
 }
 
 template <typename real>
@@ -98,7 +104,7 @@ CR_HD void prim_box_at(const Prim<real>& p, const Key<real>* keys, real t, bool 
             if (l <= h) { blo[a] = l; bhi[a] = h; } else { blo[a] = h; bhi[a] = l; }
         }
     }
-    enclose(lo, hi, blo, bhi);
+    if (box_is_number(blo, bhi)) enclose(lo, hi, blo, bhi);
 }
 
 // The sample times of the refit rule, indexed: 0 = ta, 1 = tb, then three per key (its start with the key active,

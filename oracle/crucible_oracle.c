@@ -1175,13 +1175,18 @@ static int refit_sample(const Hittable* h, real ta, real tb, int i, real* t, int
     *t = k->t1;
     return ta < k->t1 && k->t1 < tb;
 }
+/* a sample box with a coordinate that is not a number is not united (refit.hpp box_is_number) */
+static Aabb unite_sample(Aabb acc, Aabb s) {
+    if (!(s.x.min == s.x.min && s.x.max == s.x.max && s.y.min == s.y.min && s.y.max == s.y.max && s.z.min == s.z.min && s.z.max == s.z.max)) return acc;
+    return aabb_from_boxes(acc, s);
+}
 static Aabb prim_box_over(const Hittable* h, real ta, real tb) {
     if (h->kind == H_HITLIST) {   /* the visible objects' boxes, united in the list's order */
         Aabb l = aabb_empty();
         for (int i = 0; i < h->n_objs; i++) if (!h->objs[i]->hide) l = aabb_from_boxes(l, prim_box_over(h->objs[i], ta, tb));
         return l;
     }
-    Aabb b = prim_box_at(h, ta, 0);
+    Aabb b = unite_sample(aabb_empty(), prim_box_at(h, ta, 0));
     if (h->tl.n_keys == 0) return b;
     int scaled = 0;
     for (int i = 0; i < h->tl.n_keys; i++) scaled |= h->tl.keys[i].channel >= CR_KEY_SCALE_X;
@@ -1191,18 +1196,18 @@ static Aabb prim_box_over(const Hittable* h, real ta, real tb) {
             real t1, t2; int s1, s2;
             if (!refit_sample(h, ta, tb, i, &t1, &s1)) continue;
             for (int j = 0; j < n; j++)
-                if (refit_sample(h, ta, tb, j, &t2, &s2)) b = aabb_from_boxes(b, prim_box_at2(h, t1, s1, t2, s2));
+                if (refit_sample(h, ta, tb, j, &t2, &s2)) b = unite_sample(b, prim_box_at2(h, t1, s1, t2, s2));
         }
         return b;
     }
-    b = aabb_from_boxes(b, prim_box_at(h, tb, 0));
+    b = unite_sample(b, prim_box_at(h, tb, 0));
     for (int i = 0; i < h->tl.n_keys; i++) {
         const Key* k = &h->tl.keys[i];
         if (ta < k->t0 && k->t0 <= tb) {
-            b = aabb_from_boxes(b, prim_box_at(h, k->t0, 0));
-            b = aabb_from_boxes(b, prim_box_at(h, k->t0, 1));
+            b = unite_sample(b, prim_box_at(h, k->t0, 0));
+            b = unite_sample(b, prim_box_at(h, k->t0, 1));
         }
-        if (ta < k->t1 && k->t1 < tb) b = aabb_from_boxes(b, prim_box_at(h, k->t1, 0));
+        if (ta < k->t1 && k->t1 < tb) b = unite_sample(b, prim_box_at(h, k->t1, 0));
     }
     return b;
 }
