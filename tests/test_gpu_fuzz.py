@@ -134,6 +134,87 @@ def random_scene(seed, lists=False):
     return sc
 
 
+def hostile_scene(seed, lists=False):
+    """Degenerate inputs on purpose: axis-aligned camera rays (zero direction components: Aabb::hit's compare/select
+    form), coincident and zero-radius spheres (ties, empty boxes), axis-flat and zero-area triangles, huge and tiny
+    coordinates, scatter_prob 0 / negative / > 1 (division by zero, complements: the NaN policy), fuzz 1, ior 1,
+    deep checker chains, 1x1 images, depth 0."""
+    rs = np.random.RandomState(seed)
+    u = rs.uniform
+    width = int(rs.choice([1, 2, 9, 33]))
+    sc = Scene.new_image(float(rs.choice([1.0, 16.0 / 9.0, 0.5])), width, 24.0, float(rs.choice([0.0, 180.0, 360.0])), 1)
+    cam = sc.scene_cam
+    cam.set_samples(int(rs.randint(1, 4)))
+    cam.set_max_depth(int(rs.choice([0, 1, 2, 6, 50])))
+    axis_aligned = rs.rand() < 0.5
+    scale = float(rs.choice([1.0, 1.0, 1e-6, 1e6]))
+    if axis_aligned:
+        cam.look_from((0.0, 0.0, 5.0 * scale))
+        cam.look_at((0.0, 0.0, 0.0))
+        cam.set_vfov(float(rs.choice([1e-9, 1.0, 40.0])))
+    else:
+        cam.look_from(tuple(u(-6, 6, 3) * scale))
+        cam.look_at(tuple(u(-1, 1, 3) * scale))
+        cam.set_vfov(u(5, 120))
+    cam.set_defocus_angle(float(rs.choice([0.0, 0.0, 1.0])))
+    cam.set_focus_dist(5.0 * scale)
+
+    def texture(depth):
+        if depth == 0 or rs.rand() < 0.3:
+            return SolidColor(tuple(rs.choice([0.0, 1.0, 0.5], 3)))
+        return CheckerTexture.new_from_textures(float(rs.choice([1e-9, 0.3, 1e9])), texture(depth - 1), texture(depth - 1) if rs.rand() < 0.3 else SolidColor((0.2, 0.8, 0.1)))
+
+    def material():
+        k = rs.randint(0, 4)
+        if k == 0:
+            return Lambertian.new_from_texture(texture(int(rs.choice([0, 1, 3, 12]))), float(rs.choice([1.0, 0.5, 0.0, -0.5, 2.0, 1e-300])))
+        if k == 1:
+            return Metal.new(tuple(rs.choice([0.0, 1.0, 0.7], 3)), float(rs.choice([0.0, 1.0, 0.5])))
+        if k == 2:
+            return Dielectric.new(float(rs.choice([1.0, 1.5, 0.0, 1e-9, 1e9, -1.5])))
+        return Lambertian.new_from_color((0.5, 0.5, 0.5), 1.0)
+
+    elems = []
+    centre = tuple(u(-1, 1, 3) * scale)
+    for k in range(int(rs.randint(0, 9))):
+        kind = rs.randint(0, 7)
+        if kind == 0:
+            elems.append(Sphere.new(centre, float(rs.choice([0.0, 0.5, 1.0])) * scale, material()))        # coincident / zero radius
+        elif kind == 1:
+            elems.append(Sphere.new(tuple(u(-2, 2, 3) * scale), u(0.1, 1.5) * scale, material()))
+        elif kind == 2:
+            z = float(rs.choice([0.0, 1.0])) * scale
+            elems.append(Triangle.new((-scale, -scale, z), (scale, -scale, z), (0.0, scale, z), material()))  # axis-flat
+        elif kind == 3:
+            p = tuple(u(-1, 1, 3) * scale)
+            elems.append(Triangle.new(p, p, tuple(u(-1, 1, 3) * scale), material()))                         # zero area
+        elif kind == 4:
+            elems.append(Triangle.new(*(tuple(u(-2, 2, 3) * scale) for _ in range(3)), material()))
+        elif kind == 5:
+            elems.append(Sphere.new((0.0, -1000.0 * scale, 0.0), 1000.0 * scale, material()))
+        else:
+            elems.append(Sphere.new(tuple(u(-2, 2, 3) * scale), 0.7 * scale, material()))
+            if rs.rand() < 0.5:
+                elems[-1].timeline.translate_point(tuple(u(-1, 1, 3) * scale), float(rs.choice([0.0, 1e-9, 0.01])), LERP if rs.rand() < 0.5 else NERP, LOCAL)
+            else:
+                elems[-1].timeline.scale_sphere(float(rs.choice([0.0, 2.0])) * scale, float(rs.choice([0.0, 0.01])), LERP if rs.rand() < 0.5 else NERP)
+    if lists and elems:
+        cut = len(elems) // 2
+        l = HitList.new(elems[:cut]) if rs.rand() < 0.5 else HitList.default()
+        if not l.objs:
+            for e in elems[:cut]:
+                l.add(e)
+        sc.add_element(l, "l")
+        elems = elems[cut:]
+    for k, e in enumerate(elems):
+        if rs.rand() < 0.1:
+            e.hide = True
+        sc.add_element(e, f"e{k}")
+        if e.hide:
+            sc.hide_element(f"e{k}")
+    return sc
+
+
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
 @pytest.mark.parametrize("seed", list(range(36)) + list(range(100, 124)))
 def test_random_scene_bit_exact(renderer, oracles, rt, tag, seed):
@@ -156,6 +237,38 @@ def test_random_scene_bit_exact(renderer, oracles, rt, tag, seed):
         assert rst["nan_pixels"] > 0
         return
     assert rst["nan_pixels"] == 0
+    assert np.array_equal(img, ref), f"seed {seed}: {(img != ref).any(axis=2).sum()} pixels differ"
+    for k in COUNTERS:
+        assert st[k] == rst[k], (seed, k, st[k], rst[k])
+
+
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+@pytest.mark.parametrize("seed", [300052, 309589, 400541] + list(range(300000, 300045)))
+def test_hostile_scene_bit_exact(renderer, oracles, rt, tag, seed):
+    """Degenerate inputs (hostile_scene): the same equalities.  300052 / 309589: zero-length radius keys at the frame time
+    under refit_boxes (0/0 at the key's own start -- the refit rule skips that sample); 400541: an opt-in tree over a
+    scene whose only element is a list without visible objects.  scripts/fuzz_campaign.py runs tens of thousands more."""
+    try:
+        sc = hostile_scene(seed, lists=seed >= 400000 or (seed < 300045 and seed % 2 == 1))
+    except ValueError:
+        pytest.skip("the mirror's own argument checks reject this scene")
+    variant = seed % 3
+    sc.scene_cam.refit_boxes = variant == 1
+    if variant == 2:
+        sc.bvh_mode = [A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED, A.CR_BVH_LBVH][(seed // 3) % 3]
+    renderer.upload_scene(sc.flatten())
+    try:
+        img, st = renderer.render(sc.scene_cam, seed=seed, real_type=rt)
+        gpu_nan = False
+    except Exception as e:
+        assert getattr(e, "code", None) == A.CR_ERR_NAN, e
+        gpu_nan = True
+    tree = renderer.export_bvh(rt) if variant == 2 else None
+    empty = tree is not None and len(tree[1]) == 0
+    ref, rst = oracles[rt].render_image(sc, seed=seed, tree=None if empty else tree, linear_list=empty)
+    assert gpu_nan == (rst["nan_pixels"] > 0)
+    if gpu_nan:
+        return
     assert np.array_equal(img, ref), f"seed {seed}: {(img != ref).any(axis=2).sum()} pixels differ"
     for k in COUNTERS:
         assert st[k] == rst[k], (seed, k, st[k], rst[k])
