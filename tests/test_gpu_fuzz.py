@@ -215,6 +215,56 @@ def hostile_scene(seed, lists=False):
     return sc
 
 
+def big_scene(seed, lists=False):
+    """Hundreds to tens of thousands of primitives: trees that do not fit in LDS (the top-levels window, the all-global
+    kernels, the f32 entry point for more than 65 536 wrappers), long list elements, keyed primitives among static ones."""
+    rs = np.random.RandomState(seed)
+    u = rs.uniform
+    n = int(rs.choice([300, 1500, 6000, 40000]))
+    sc = Scene.new_image(16.0 / 9.0, int(rs.choice([24, 40])), 24.0, float(rs.choice([180.0, 360.0])), 1)
+    cam = sc.scene_cam
+    cam.set_samples(int(rs.randint(1, 3)))
+    cam.set_max_depth(int(rs.choice([2, 8, 50])))
+    cam.look_from((u(-3, 3), u(1, 6), u(8, 14)))
+    cam.look_at((0.0, 0.5, 0.0))
+    cam.set_vfov(u(20, 50))
+    cam.set_defocus_angle(float(rs.choice([0.0, 0.6])))
+    cam.frame = int(rs.randint(0, 2))
+    mats = [Lambertian.new_from_color(tuple(u(0.1, 0.9, 3)), 1.0), Metal.new(tuple(u(0.5, 1.0, 3)), 0.1), Dielectric.new(1.5),
+            Lambertian.new_from_texture(CheckerTexture.new_from_color(0.3, (0.2, 0.3, 0.1), (0.9, 0.9, 0.9)), 1.0)]
+    sc.add_element(Sphere.new((0.0, -1000.0, 0.0), 1000.0, mats[3]), "ground")
+    span = 2.0 + n ** 0.5 * 0.25
+    members = []
+    keyed = []
+    for k in range(n):
+        m = mats[int(rs.randint(0, 3))]
+        if rs.rand() < 0.7:
+            o = Sphere.new((u(-span, span), u(0.05, 0.4), u(-span, span)), u(0.03, 0.2), m)
+        else:
+            c = np.array([u(-span, span), u(0.0, 0.6), u(-span, span)])
+            o = Triangle.new(*(tuple(c + u(-0.3, 0.3, 3)) for _ in range(3)), m)
+        if rs.rand() < 0.01:
+            o.timeline.translate_point(tuple(u(-0.5, 0.5, 3)), float(rs.choice([0.01, 0.5, 1.5])), LERP if rs.rand() < 0.5 else NERP, LOCAL)
+        if lists and rs.rand() < 0.3:
+            o.hide = rs.rand() < 0.05
+            members.append(o)
+        else:
+            sc.add_element(o, f"p{k}")
+            if rs.rand() < 0.02:
+                sc.hide_element(f"p{k}")
+    if lists:
+        cuts = sorted(rs.randint(0, len(members) + 1, size=3))
+        for li, (a, b) in enumerate(zip([0] + cuts, cuts + [len(members)])):
+            if rs.rand() < 0.3:
+                l = HitList.new(members[a:b])
+            else:
+                l = HitList.default()
+                for o in members[a:b]:
+                    l.add(o)
+            sc.add_element(l, f"l{li}")
+    return sc
+
+
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
 @pytest.mark.parametrize("seed", list(range(36)) + list(range(100, 124)))
 def test_random_scene_bit_exact(renderer, oracles, rt, tag, seed):
@@ -269,6 +319,24 @@ def test_hostile_scene_bit_exact(renderer, oracles, rt, tag, seed):
     assert gpu_nan == (rst["nan_pixels"] > 0)
     if gpu_nan:
         return
+    assert np.array_equal(img, ref), f"seed {seed}: {(img != ref).any(axis=2).sum()} pixels differ"
+    for k in COUNTERS:
+        assert st[k] == rst[k], (seed, k, st[k], rst[k])
+
+
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+@pytest.mark.parametrize("seed", range(500000, 500012))
+def test_big_scene_bit_exact(renderer, oracles, rt, tag, seed):
+    """big_scene: trees outside LDS, with and without lists, refit and the opt-in trees by the same rota as above."""
+    sc = big_scene(seed, lists=seed % 2 == 1)
+    variant = seed % 3
+    sc.scene_cam.refit_boxes = variant == 1
+    if variant == 2:
+        sc.bvh_mode = [A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED, A.CR_BVH_LBVH][(seed // 3) % 3]
+    renderer.upload_scene(sc.flatten())
+    img, st = renderer.render(sc.scene_cam, seed=seed, real_type=rt)
+    tree = renderer.export_bvh(rt) if variant == 2 else None
+    ref, rst = oracles[rt].render_image(sc, seed=seed, tree=tree)
     assert np.array_equal(img, ref), f"seed {seed}: {(img != ref).any(axis=2).sum()} pixels differ"
     for k in COUNTERS:
         assert st[k] == rst[k], (seed, k, st[k], rst[k])
