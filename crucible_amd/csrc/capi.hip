@@ -1379,6 +1379,9 @@ int32_t cr_upload_scene(CrHandle* h, const CrSceneDesc* s) {
     if (s->n_prims < 0 || s->n_materials < 0 || s->n_textures < 0 || s->n_images < 0 || s->n_keys < 0)
         return fail(h, CR_ERR_INVALID_ARG, "negative count");
     if (s->n_prims >= (1 << 29)) return fail(h, CR_ERR_INVALID_ARG, "too many primitives");
+    if ((s->n_prims > 0 && !s->prims) || (s->n_materials > 0 && !s->materials) || (s->n_textures > 0 && !s->textures) ||
+        (s->n_images > 0 && !s->images) || (s->n_keys > 0 && !s->keys))
+        return fail(h, CR_ERR_INVALID_ARG, "a descriptor array is null although its count is not zero");
     auto finite = [](double x) { return x == x && x != HUGE_VAL && x != -HUGE_VAL; };
     for (int i = 0; i < s->n_textures; i++) {
         const CrTexture& t = s->textures[i];

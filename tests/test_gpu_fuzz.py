@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from crucible_amd import _abi as A
+from crucible_amd.renderer import CrucibleError
 from crucible_amd.scene import (LERP, LOCAL, NERP, WORLD, CheckerTexture, Dielectric, HitList, ImageTexture, Lambertian, Metal,
                                 RTWImage, Scene, SolidColor, Sphere, Triangle)
 
@@ -340,3 +341,77 @@ def test_big_scene_bit_exact(renderer, oracles, rt, tag, seed):
     assert np.array_equal(img, ref), f"seed {seed}: {(img != ref).any(axis=2).sum()} pixels differ"
     for k in COUNTERS:
         assert st[k] == rst[k], (seed, k, st[k], rst[k])
+
+
+def _mutations(flat, rs):
+    """(label, edit) pairs: every edit makes the descriptor invalid in a way cr_upload_scene must answer with a status
+    code (include/crucible_hip.h: 'status codes instead of panics')."""
+    d = flat.desc
+    out = []
+    nan, inf = float("nan"), float("inf")
+    if d.n_prims:
+        i = int(rs.randint(0, d.n_prims))
+        p = flat.prims[i]
+        if p.kind != A.CR_PRIM_LIST:
+            out += [("prim kind", lambda: setattr(p, "kind", int(rs.choice([7, -1])))),
+                    ("prim material", lambda: setattr(p, "material", int(rs.choice([d.n_materials, -1, 1 << 30])))),
+                    ("prim key range", lambda: (setattr(p, "key_first", d.n_keys), setattr(p, "key_count", 1))),
+                    ("prim key count", lambda: setattr(p, "key_count", -1)),
+                    ("prim coordinate", lambda: p.v.__setitem__(int(rs.randint(0, 3)), float(rs.choice([nan, inf, -inf]))))]
+            if p.kind == A.CR_PRIM_SPHERE:
+                out.append(("negative radius", lambda: p.v.__setitem__(3, -0.5)))
+    if d.n_materials:
+        m = flat.materials[int(rs.randint(0, d.n_materials))]
+        out += [("material kind", lambda: setattr(m, "kind", 9)), ("material param", lambda: setattr(m, "param", nan))]
+        if m.kind == A.CR_MAT_LAMBERTIAN:
+            out.append(("material texture", lambda: setattr(m, "texture", int(rs.choice([d.n_textures, -1])))))
+        if m.kind == A.CR_MAT_METAL:
+            out += [("metal fuzz", lambda: setattr(m, "param", float(rs.choice([1.5, -0.1])))), ("metal albedo", lambda: m.albedo.__setitem__(1, 1.5))]
+    if d.n_textures:
+        j = int(rs.randint(0, d.n_textures))
+        x = flat.textures[j]
+        out.append(("texture kind", lambda: setattr(x, "kind", 5)))
+        if x.kind == A.CR_TEX_CHECKER:
+            out += [("checker child", lambda: setattr(x, "even", int(rs.choice([j, d.n_textures, -1])))), ("checker child", lambda: setattr(x, "odd", j))]
+        elif x.kind == A.CR_TEX_IMAGE:
+            out.append(("texture image", lambda: setattr(x, "image", int(rs.choice([d.n_images, -1])))))
+        else:
+            out.append(("solid colour", lambda: x.color.__setitem__(0, float(rs.choice([-0.1, 1.1, nan])))))
+    if d.n_keys:
+        k = flat.keys[int(rs.randint(0, d.n_keys))]
+        out += [("key channel", lambda: setattr(k, "channel", int(rs.choice([9, -1])))), ("key interp", lambda: setattr(k, "interp", 3))]
+    if d.n_images:
+        out.append(("image size", lambda: setattr(flat.images[0], "width", 0)))
+    out += [("negative count", lambda: setattr(d, str(rs.choice(["n_prims", "n_materials", "n_textures", "n_images", "n_keys"])), -1)),
+            ("sky kind", lambda: setattr(d, "sky_kind", 3)), ("bvh mode", lambda: setattr(d, "bvh_mode", 9)),
+            ("sky image", lambda: (setattr(d, "sky_kind", A.CR_SKY_SPHERICAL), setattr(d, "sky_image", d.n_images)))]
+    if d.n_prims:
+        out.append(("null array", lambda: setattr(d, "prims", None)))
+    if d.n_materials:
+        out.append(("null array", lambda: setattr(d, "materials", None)))
+    return out
+
+
+@pytest.mark.parametrize("seed", range(700000, 700060))
+def test_mutated_descriptors_are_refused(renderer, oracles, seed):
+    """One invalid field at a time in an otherwise valid random descriptor: cr_upload_scene answers CR_ERR_INVALID_ARG (or
+    _UNSUPPORTED), never crashes, and the handle keeps working -- the scene it held still renders the oracle's image."""
+    rs = np.random.RandomState(seed)
+    sc = random_scene(1000 + seed % 60, lists=seed % 2 == 1)
+    good = sc.flatten()
+    renderer.upload_scene(good)
+    for _ in range(6):
+        flat = sc.flatten()
+        options = _mutations(flat, rs)
+        label, edit = options[int(rs.randint(0, len(options)))]
+        edit()
+        with pytest.raises(CrucibleError) as e:
+            renderer.upload_scene(flat)
+        assert e.value.code in (A.CR_ERR_INVALID_ARG, A.CR_ERR_UNSUPPORTED), (label, e.value)
+    try:
+        img, _ = renderer.render(sc.scene_cam, seed=seed, real_type=A.CR_REAL_F32)
+    except CrucibleError as e:
+        assert e.code == A.CR_ERR_NAN
+        return
+    ref, rst = oracles[A.CR_REAL_F32].render_image(sc, seed=seed)
+    assert np.array_equal(img, ref)
