@@ -415,3 +415,54 @@ def test_mutated_descriptors_are_refused(renderer, oracles, seed):
         return
     ref, rst = oracles[A.CR_REAL_F32].render_image(sc, seed=seed)
     assert np.array_equal(img, ref)
+
+
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+@pytest.mark.parametrize("seed", range(800000, 800016))
+def test_random_sample_shards_and_groups(renderer, oracles, monkeypatch, rt, tag, seed):
+    """SURVEY 8(e) on random scenes: a random partition of the sample range into shards (empty ones included), each
+    rendered as a per-pixel SUM and compared with the oracle's sum of the same samples bit for bit; then the library's
+    own group over a random member count (members sharing this box's one device) against its shard sums added in member order."""
+    from crucible_amd.group import RenderGroup, shard
+    monkeypatch.setenv("CRUCIBLE_GROUP_SAME_DEVICE", "1")
+    rs = np.random.RandomState(seed)
+    sc = random_scene(1000 + seed % 97, lists=seed % 2 == 1)
+    cam = sc.scene_cam
+    spp = int(rs.randint(1, 10))
+    cam.set_samples(spp)
+    flat = sc.flatten()
+    renderer.upload_scene(flat)
+    cuts = sorted(int(c) for c in rs.randint(0, spp + 1, size=int(rs.randint(0, 4))))
+    h = oracles[rt].scene_create(flat)
+    try:
+        for b, e in zip([0] + cuts, cuts + [spp]):
+            try:
+                part, st = renderer.render(cam, seed=seed, real_type=rt, sample_begin=b, sample_count=e - b, output_sum=True)
+            except CrucibleError as err:
+                assert err.code == A.CR_ERR_NAN
+                return
+            ref, rst = oracles[rt].render(h, cam, seed=seed, sample_begin=b, sample_count=e - b, output_sum=True)
+            assert np.array_equal(part.reshape(-1, 3), ref), (seed, b, e)
+            for k in COUNTERS:
+                assert st[k] == rst[k], (seed, b, e, k)
+    finally:
+        oracles[rt].scene_destroy(h)
+    members = int(rs.randint(1, 7))
+    total = None
+    for m in range(members):
+        b, n = shard(spp, m, members)
+        part, _ = renderer.render(cam, seed=seed, real_type=rt, sample_begin=b, sample_count=n, output_sum=True)
+        total = part.copy() if total is None else total + part
+    expect = total / total.dtype.type(spp)
+    g = RenderGroup.local([0] * members)
+    try:
+        g.upload_scene(flat)
+        try:
+            img, gst = g.render(cam, seed=seed, real_type=rt)
+        except CrucibleError as err:
+            assert err.code == A.CR_ERR_NAN
+            return
+        assert gst["members"] == members
+        assert np.array_equal(img, expect, equal_nan=True)
+    finally:
+        g.close()
