@@ -61,6 +61,7 @@ template <typename real> struct DevScene {
     bool animated = false;
     bool has_triangles = false;
     bool has_leaf_runs = false;              // some leaf names its primitives through leaf_runs (a HitList element)
+    bool has_bvh_elements = false;           // CR_BVH_REFERENCE over a BVHWrapper element: the records are not the reference's wrappers one to one (no export)
     bool has_lists = false;                  // the tree was built over at least one HitList element: its construction-time box
                                              // (empty, or grown over hidden objects too) is not what refit derives
     DevBuf entries_refit;                    // working copy whose boxes refit_level_kernel rewrites per frame
@@ -523,17 +524,23 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
     auto lap = [&](const char* what) { if (timing) fprintf(stderr, "[build] %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };
     // The objects the BVH build sees, in list order (bvhwrapper.rs:16-26): visible spheres and triangles, and every
     // list whatever it holds.  Under the opt-in trees a list's visible objects stand in for it.
-    struct Obj { int32_t desc, first, count; };   // count < 0: a primitive
+    struct Obj { int32_t desc, first, count, inner; };   // count < 0: a primitive; inner >= 0: a BVHWrapper element (index into `inners`)
     const bool ref_tree = h->bvh_mode == CR_BVH_REFERENCE;
     std::vector<Obj> objs;
+    std::vector<std::vector<int32_t>> inner_members;   // per BVHWrapper element: its visible objects (descriptor indices)
     for (size_t i = 0; i < h->prims.size(); i++) {
         const CrPrimitive& p = h->prims[i];
         if (p.flags & CR_PRIM_MEMBER) continue;
-        if (p.kind == CR_PRIM_LIST) {
+        if (p.kind == CR_PRIM_LIST || p.kind == CR_PRIM_BVH) {
             const int32_t first = (int32_t)p.v[0], count = (int32_t)p.v[1];
-            if (ref_tree) objs.push_back({(int32_t)i, first, count});
-            else for (int32_t k = first; k < first + count; k++) if (!(h->prims[k].flags & CR_PRIM_HIDDEN)) objs.push_back({k, 0, -1});
-        } else if (!(p.flags & CR_PRIM_HIDDEN)) objs.push_back({(int32_t)i, 0, -1});
+            if (!ref_tree) { for (int32_t k = first; k < first + count; k++) if (!(h->prims[k].flags & CR_PRIM_HIDDEN)) objs.push_back({k, 0, -1, -1}); continue; }
+            if (p.kind == CR_PRIM_LIST) { objs.push_back({(int32_t)i, first, count, -1}); continue; }
+            std::vector<int32_t> vis;   // new_wrapper drops the hidden objects (bvhwrapper.rs:16-26)
+            for (int32_t k = first; k < first + count; k++) if (!(h->prims[k].flags & CR_PRIM_HIDDEN)) vis.push_back(k);
+            if (vis.empty()) { objs.push_back({(int32_t)i, first, 0, -1}); continue; }   // ... and returns an empty list for none (:28-30)
+            objs.push_back({(int32_t)i, first, count, (int32_t)inner_members.size()});
+            inner_members.push_back(std::move(vis));
+        } else if (!(p.flags & CR_PRIM_HIDDEN)) objs.push_back({(int32_t)i, 0, -1, -1});
     }
     const int32_t n = (int32_t)objs.size();
     Builder<real> b;
@@ -567,6 +574,25 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
             }
         }
     };
+    // BVHWrapper elements: the inner trees, by the reference's own build over their visible objects
+    std::vector<Builder<real>> inners(inner_members.size());
+    std::vector<std::vector<Prim<real>>> inner_src(inner_members.size());
+    for (size_t w = 0; w < inners.size(); w++) {
+        const std::vector<int32_t>& mem = inner_members[w];
+        const int32_t m = (int32_t)mem.size();
+        Builder<real>& ib = inners[w];
+        for (int a = 0; a < 3; a++) { ib.bmin[a].resize(m); ib.bmax[a].resize(m); }
+        ib.order.resize(m);
+        inner_src[w].resize(m);
+        for (int32_t k = 0; k < m; k++) {
+            inner_src[w][k] = make_prim(h->prims[mem[k]]);
+            real lo[3], hi[3];
+            prim_box(inner_src[w][k], lo, hi);
+            for (int a = 0; a < 3; a++) { ib.bmin[a][k] = lo[a]; ib.bmax[a][k] = hi[a]; }
+            ib.order[k] = k;
+        }
+        ib.build_root(m);
+    }
     for (int32_t i = 0; i < n; i++) {
         const Obj& o = objs[i];
         b.order[i] = i;
@@ -574,6 +600,9 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
         if (o.count < 0) {
             src[i] = make_prim(h->prims[o.desc]);
             prim_box(src[i], lo, hi);
+        } else if (o.inner >= 0) {   // the wrapper's box: its root's (new_from_vec, bvhwrapper.rs:39)
+            const Entry<real>& root = inners[o.inner].entries[0];
+            for (int a = 0; a < 3; a++) { lo[a] = root.b[2 * a]; hi[a] = root.b[2 * a + 1]; }
         } else {   // HitList: Aabb::default() (hitlist.rs:13-18), grown by add() over every object, hidden or not (hitlist.rs:24-27)
             any_lists = true;
             for (int a = 0; a < 3; a++) { lo[a] = std::numeric_limits<real>::infinity(); hi[a] = -std::numeric_limits<real>::infinity(); }
@@ -594,6 +623,10 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
         for (int a = 0; a < 3; a++) { b.bmin[a][i] = lo[a]; b.bmax[a][i] = hi[a]; }
     }
     std::vector<int8_t> axis;
+    struct Run { int32_t first, count; bool pseudo; };
+    std::vector<Run> spliced_runs;              // scenes with a BVHWrapper element: the primitive run of every leaf record
+    std::vector<Prim<real>> spliced_prims;      // ... and the primitive records in the order the runs name them
+    bool spliced = false;
     ds.ordered = h->bvh_mode == CR_BVH_SAH_ORDERED;
     lap("primitive records and boxes");
     const bool lbvh = h->bvh_mode == CR_BVH_LBVH;
@@ -606,7 +639,75 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
         sb.build_root(n);
         sb.linearise(b.entries, axis);
         relayout_bfs(b.entries, ds.level_begin, &axis);
-    } else if (n > 0) { b.build_root(n); relayout_bfs(b.entries, ds.level_begin); }
+    } else if (n > 0) {
+        b.build_root(n);
+        if (!inners.empty()) {
+            // A leaf wrapper that holds a BVHWrapper element becomes an inner record: the element's own tree is spliced in
+            // as one child; a primitive or list beside it becomes a record of its own with an empty box (which the box
+            // test always passes, bvh.rs:96-130 -- BVHWrapper::hit tests that child without any box), and a span-1
+            // wrapper (the element twice, bvhwrapper.rs:56-58) gets an empty record as its second child: the second walk
+            // of the same tree cannot find anything closer.  Every leaf names its primitive run through `runs`.
+            std::vector<Entry<real>> sp;
+            std::function<void(int32_t)> emit;
+            auto new_run = [&](int32_t first, int32_t count, bool pseudo) { spliced_runs.push_back({first, count, pseudo}); return (int32_t)spliced_runs.size() - 1; };
+            auto append_obj = [&](const Obj& o, int32_t order_pos) {
+                if (o.count < 0) spliced_prims.push_back(src[order_pos]);
+                else for (int32_t k = o.first; k < o.first + o.count; k++) if (!(h->prims[k].flags & CR_PRIM_HIDDEN)) spliced_prims.push_back(make_prim(h->prims[k]));
+            };
+            const real inf = std::numeric_limits<real>::infinity();
+            auto pseudo_leaf = [&](int32_t first, int32_t count) {
+                Entry<real> pe;
+                for (int a = 0; a < 3; a++) { pe.b[2 * a] = inf; pe.b[2 * a + 1] = -inf; }
+                pe.leaf = new_run(first, count, true);
+                pe.skip = (int32_t)sp.size() + 1;
+                sp.push_back(pe);
+            };
+            emit = [&](int32_t i) {
+                const Entry<real> e = b.entries[i];
+                const int32_t idx = (int32_t)sp.size();
+                sp.push_back(e);
+                if (e.leaf < 0) { emit(i + 1); emit(b.entries[i + 1].skip); sp[idx].skip = (int32_t)sp.size(); return; }
+                const int32_t start = e.leaf >> 1, span = (e.leaf & 1) + 1;
+                bool any_inner = false;
+                for (int32_t k = 0; k < span; k++) any_inner |= objs[b.order[start + k]].inner >= 0;
+                if (!any_inner) {
+                    const int32_t first = (int32_t)spliced_prims.size();
+                    for (int32_t k = 0; k < span; k++) append_obj(objs[b.order[start + k]], b.order[start + k]);
+                    sp[idx].leaf = new_run(first, (int32_t)spliced_prims.size() - first, false);
+                    sp[idx].skip = idx + 1;
+                    return;
+                }
+                sp[idx].leaf = -1;
+                for (int32_t k = 0; k < span; k++) {
+                    const Obj& o = objs[b.order[start + k]];
+                    if (o.inner < 0) {
+                        const int32_t first = (int32_t)spliced_prims.size();
+                        append_obj(o, b.order[start + k]);
+                        pseudo_leaf(first, (int32_t)spliced_prims.size() - first);
+                        continue;
+                    }
+                    const Builder<real>& ib = inners[o.inner];
+                    const int32_t base = (int32_t)sp.size();
+                    for (const Entry<real>& ie : ib.entries) {
+                        Entry<real> c = ie;
+                        c.skip += base;
+                        if (c.leaf >= 0) {
+                            const int32_t s0 = c.leaf >> 1, cnt = (c.leaf & 1) + 1, first = (int32_t)spliced_prims.size();
+                            for (int32_t q = 0; q < cnt; q++) spliced_prims.push_back(inner_src[o.inner][ib.order[s0 + q]]);
+                            c.leaf = new_run(first, cnt, false);
+                        }
+                        sp.push_back(c);
+                    }
+                }
+                if (span == 1) pseudo_leaf((int32_t)spliced_prims.size(), 0);
+                sp[idx].skip = (int32_t)sp.size();
+            };
+            emit(0);
+            b.entries.swap(sp);
+            spliced = true;
+        }
+        relayout_bfs(b.entries, ds.level_begin);
+    }
     else ds.level_begin.assign(1, 0);
     lap("tree");
     // Primitive records in leaf order; a list contributes its visible objects in the list's order (a hidden object
@@ -614,19 +715,28 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
     std::vector<Prim<real>> leaf_prims;
     leaf_prims.reserve(n);
     std::vector<int32_t> first_of((size_t)n + 1);
-    for (int32_t i = 0; i < n; i++) {
+    if (spliced) leaf_prims.swap(spliced_prims);
+    else for (int32_t i = 0; i < n; i++) {
         const Obj& o = objs[b.order[i]];
         first_of[i] = (int32_t)leaf_prims.size();
         if (o.count < 0) leaf_prims.push_back(src[b.order[i]]);
         else for (int32_t k = o.first; k < o.first + o.count; k++) if (!(h->prims[k].flags & CR_PRIM_HIDDEN)) leaf_prims.push_back(make_prim(h->prims[k]));
     }
-    first_of[n] = (int32_t)leaf_prims.size();
+    if (!spliced) first_of[n] = (int32_t)leaf_prims.size();
     if (leaf_prims.size() >= ((size_t)1 << 29)) return fail(h, CR_ERR_INVALID_ARG, "too many primitives");
     // What the device walks: a leaf wrapper names a run of primitive records.  One or two records fit the wrapper
     // itself; a leaf that holds a list names its run through the side table (first, count).
     std::vector<Entry<real>> dev_entries;
     std::vector<int32_t> leaf_runs;
-    if (any_lists) {
+    if (spliced) {
+        dev_entries = b.entries;
+        for (Entry<real>& e : dev_entries) {
+            if (e.leaf < 0) continue;
+            const Run r = spliced_runs[e.leaf];
+            if (!r.pseudo && (r.count == 1 || r.count == 2)) e.leaf = (r.first << 1) | (r.count - 1);
+            else { e.leaf = kLeafRun | (r.pseudo ? kLeafPseudo : 0) | (int32_t)(leaf_runs.size() / 2); leaf_runs.push_back(r.first); leaf_runs.push_back(r.count); }
+        }
+    } else if (any_lists) {
         dev_entries = b.entries;
         for (Entry<real>& e : dev_entries) {
             if (e.leaf < 0) continue;
@@ -636,7 +746,7 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
             else { e.leaf = kLeafRun | (int32_t)(leaf_runs.size() / 2); leaf_runs.push_back(first); leaf_runs.push_back(count); }
         }
     }
-    const std::vector<Entry<real>>& up_entries = any_lists ? dev_entries : b.entries;
+    const std::vector<Entry<real>>& up_entries = (any_lists || spliced) ? dev_entries : b.entries;
 
     // Device texture table: only textures a non-solid lambertian can reach (a solid top-level
     // texture is folded into its material), re-indexed densely; children keep smaller indices.
@@ -743,6 +853,7 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
     ds.host_axis = axis;
     ds.leaf_desc.resize(n);
     for (int32_t i = 0; i < n; i++) ds.leaf_desc[i] = objs[b.order[i]].desc;
+    ds.has_bvh_elements = spliced;
     ds.built = true;
     h->upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return CR_OK;
@@ -1261,6 +1372,7 @@ int32_t export_bvh(CrHandle* h, double* boxes, int32_t* children, int32_t* split
     int32_t rc = build_dev_scene<real>(h);
     if (rc != CR_OK) return rc;
     const DevScene<real>& ds = dev_scene<real>(h);
+    if (ds.has_bvh_elements) return fail(h, CR_ERR_UNSUPPORTED, "cr_export_bvh: the scene holds a BVHWrapper element (CR_BVH_REFERENCE): its records are not two-children wrappers");
     const std::vector<Entry<real>>& E = ds.host_entries;
     *n_out = (int32_t)E.size();
     if (!boxes || !children || capacity < (int32_t)E.size()) return E.empty() || (!boxes && !children) ? CR_OK : fail(h, CR_ERR_INVALID_ARG, "cr_export_bvh: capacity too small");
@@ -1422,8 +1534,9 @@ int32_t cr_upload_scene(CrHandle* h, const CrSceneDesc* s) {
         std::vector<char> owned((size_t)std::max(0, s->n_prims), 0);
         for (int i = 0; i < s->n_prims; i++) {
             const CrPrimitive& p = s->prims[i];
-            if (p.kind != CR_PRIM_LIST) continue;
+            if (p.kind != CR_PRIM_LIST && p.kind != CR_PRIM_BVH) continue;
             if (p.flags & (CR_PRIM_MEMBER | CR_PRIM_HIDDEN)) return fail(h, CR_ERR_INVALID_ARG, "a list is a scene element: it cannot be hidden or be an object of a list");
+            if (p.kind == CR_PRIM_BVH && (p.flags & CR_LIST_EMPTY_BOX)) return fail(h, CR_ERR_INVALID_ARG, "CR_LIST_EMPTY_BOX applies to lists");
             const double first = p.v[0], count = p.v[1];
             if (!(first >= 0.0 && count >= 0.0 && first == std::floor(first) && count == std::floor(count) && first + count <= (double)s->n_prims))
                 return fail(h, CR_ERR_INVALID_ARG, "list object range out of bounds");
@@ -1440,7 +1553,7 @@ int32_t cr_upload_scene(CrHandle* h, const CrSceneDesc* s) {
     }
     for (int i = 0; i < s->n_prims; i++) {
         const CrPrimitive& p = s->prims[i];
-        if (p.kind == CR_PRIM_LIST) continue;
+        if (p.kind == CR_PRIM_LIST || p.kind == CR_PRIM_BVH) continue;
         if (p.kind != CR_PRIM_SPHERE && p.kind != CR_PRIM_TRIANGLE) return fail(h, CR_ERR_INVALID_ARG, "unknown primitive kind");
         if (p.material < 0 || p.material >= s->n_materials) return fail(h, CR_ERR_INVALID_ARG, "primitive material index out of range");
         if (p.key_count < 0 || p.key_first < 0 || p.key_first + p.key_count > s->n_keys) return fail(h, CR_ERR_INVALID_ARG, "primitive keyframe range out of bounds");

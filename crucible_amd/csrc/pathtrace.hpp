@@ -143,7 +143,7 @@ template <typename real> CR_HD V3<real> random_unit_vector(uint64_t& s) {   // u
 // leaf < 0: inner wrapper, left child = -leaf.  leaf >= 0: span-1 or span-2 wrapper whose
 // children are primitives: first = leaf >> 1, count = (leaf & 1) + 1, in leaf order.
 // leaf >= 0 with kLeafRun set: a leaf that holds a HitList element; its primitives are the run
-// (first, count) = leaf_runs[2 * (leaf & ~kLeafRun)], [.. + 1] -- the list's visible objects and the wrapper's other
+// (first, count) = leaf_runs[2 * (leaf & kLeafRunIndex)], [.. + 1] -- the list's visible objects and the wrapper's other
 // child in the order BVHWrapper::hit and HitList::hit visit them (bvhwrapper.rs:108-120, hitlist.rs:55-61).
 // Entries are stored level by level (BFS), so the first K entries are the top of the tree:
 // scenes too large for LDS keep those K in LDS and read the rest through L2.
@@ -167,6 +167,8 @@ template <typename real> struct alignas(16) EntryO {
 template <typename real, bool ORD> struct EntryOf { using type = Entry<real>; };
 template <typename real> struct EntryOf<real, true> { using type = EntryO<real>; };
 constexpr int32_t kLeafRun = 0x40000000;
+constexpr int32_t kLeafPseudo = 0x20000000;   // with kLeafRun: the record stands for a primitive / list that BVHWrapper::hit tests without a box
+constexpr int32_t kLeafRunIndex = 0x1fffffff;
 CR_HD int32_t ordered_left(int32_t leaf) { return (-leaf) >> 2; }
 CR_HD int32_t ordered_near(int32_t leaf, int32_t oct) { const int32_t v = -leaf; return (v >> 2) + ((oct >> (v & 3)) & 1); }
 
@@ -997,7 +999,7 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
             const int32_t first = leaf >> 1, count = (leaf & 1) + 1;
             for (int32_t k = 0; k < count; k++) test(first + k);
         } else {
-            const int32_t first = A.leaf_runs[2 * (leaf & ~kLeafRun)], count = A.leaf_runs[2 * (leaf & ~kLeafRun) + 1];
+            const int32_t first = A.leaf_runs[2 * (leaf & kLeafRunIndex)], count = A.leaf_runs[2 * (leaf & kLeafRunIndex) + 1];
             for (int32_t k = 0; k < count; k++) test(first + k);
         }
     }

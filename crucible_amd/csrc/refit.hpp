@@ -165,16 +165,27 @@ __global__ void refit_level_kernel(typename EntryOf<real, ORD>::type* entries, i
     for (int a = 0; a < 3; a++) { lo[a] = r_inf(real(0)); hi[a] = -r_inf(real(0)); }
     if (leaf >= 0) {
         int32_t first = leaf >> 1, count = (leaf & 1) + 1;
-        if (leaf & kLeafRun) { first = leaf_runs[2 * (leaf & ~kLeafRun)]; count = leaf_runs[2 * (leaf & ~kLeafRun) + 1]; }
+        if (leaf & kLeafRun) { first = leaf_runs[2 * (leaf & kLeafRunIndex)]; count = leaf_runs[2 * (leaf & kLeafRunIndex) + 1]; }
+        if ((leaf & kLeafRun) && (leaf & kLeafPseudo)) count = 0;   // tested without a box in the reference: the box stays empty
         for (int32_t k = 0; k < count; k++) prim_box_over(prims[first + k], keys, ta, tb, lo, hi, use_keys != 0);
     } else {
         const int32_t li = ORD ? ordered_left(leaf) : -leaf;   // siblings are adjacent in the level-order array
-        const real* l = entries[li].b;
-        const real* r = entries[li + 1].b;
-        const real llo[3] = {l[0], l[2], l[4]}, lhi[3] = {l[1], l[3], l[5]};
-        const real rlo[3] = {r[0], r[2], r[4]}, rhi[3] = {r[1], r[3], r[5]};
-        enclose(lo, hi, llo, lhi);
-        enclose(lo, hi, rlo, rhi);
+        for (int32_t c = li; c <= li + 1; c++) {
+            const int32_t cl = entries[c].leaf;
+            if (cl >= 0 && (cl & kLeafRun) && (cl & kLeafPseudo)) {
+                // a primitive / list beside a BVHWrapper element: its own record keeps the empty box (the reference tests it
+                // without one), but the wrapper above it spans it
+                const int32_t first = leaf_runs[2 * (cl & kLeafRunIndex)], count = leaf_runs[2 * (cl & kLeafRunIndex) + 1];
+                real clo[3], chi[3];
+                for (int a = 0; a < 3; a++) { clo[a] = r_inf(real(0)); chi[a] = -r_inf(real(0)); }
+                for (int32_t k = 0; k < count; k++) prim_box_over(prims[first + k], keys, ta, tb, clo, chi, use_keys != 0);
+                enclose(lo, hi, clo, chi);
+                continue;
+            }
+            const real* cb = entries[c].b;
+            const real clo[3] = {cb[0], cb[2], cb[4]}, chi[3] = {cb[1], cb[3], cb[5]};
+            enclose(lo, hi, clo, chi);
+        }
     }
     real* b = entries[i].b;
     b[0] = lo[0]; b[1] = hi[0]; b[2] = lo[1]; b[3] = hi[1]; b[4] = lo[2]; b[5] = hi[2];

@@ -159,7 +159,7 @@ def teapot_as_list(threads=1, image_width=400, samples=200):
     """Not in the reference's demos: the teapot handed to the scene as ONE HitList element (what
     `scene.add_element(Hittables::HitList(load_obj(..)), ..)` gives, scene/mod.rs:164-166) next to a HitList::new(vec)
     list (empty box), a list inside a list with a hidden object, and ordinary elements."""
-    from .scene import HitList, load_obj
+    from .scene import BVHWrapper, HitList, load_obj
     sc = Scene.new_image(16.0 / 9.0, image_width, 24, 180.0, threads)
     cam = sc.scene_cam
     cam.set_samples(samples)
@@ -183,6 +183,9 @@ def teapot_as_list(threads=1, image_width=400, samples=200):
     outer.add(inner)
     sc.add_element(outer, "outer")
     sc.add_element(HitList.default(), "nothing")
+    # ... and a pre-built BVHWrapper as an element (scene/mod.rs:161-163)
+    sc.add_element(BVHWrapper.new_wrapper(HitList.new([Sphere.new((1.5, 0.3, 3.0), 0.3, matte), Sphere.new((0.6, 0.3, 3.4), 0.3, glass),
+                                                       Sphere.new((-0.4, 0.3, 3.6), 0.3, matte)])), "wrapped")
     return sc
 
 

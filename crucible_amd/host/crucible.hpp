@@ -240,6 +240,18 @@ struct Hittables {   // Hittables::{Sphere,Triangle,HitList}
     std::vector<Hittables> objs;
     size_t n_new = 0, n_added = 0;
     bool stale_box = false;
+    // BVHWrapper::new_wrapper(list) as a scene element (bvhwrapper.rs:15-32, scene/mod.rs:161-163): the list's visible spheres
+    // and triangles (the library rebuilds the tree from them); none visible -> the empty list the reference returns.
+    static Hittables bvh_wrapper(const Hittables& list) {
+        list.need_list();
+        Hittables h; h.kind = CR_PRIM_BVH; h.id = (size_t)-1;
+        for (const Hittables& o : list.objs) {
+            if (o.kind != CR_PRIM_SPHERE && o.kind != CR_PRIM_TRIANGLE) throw std::invalid_argument("a BVHWrapper element may hold spheres and triangles only");
+            if (!o.hide) h.objs.push_back(o);
+        }
+        if (h.objs.empty()) return hit_list();
+        return h;
+    }
     static Hittables hit_list(std::vector<Hittables> objs = {}) {   // HitList::new / HitList::default
         Hittables h; h.kind = CR_PRIM_LIST; h.id = (size_t)-1; h.objs = std::move(objs); h.n_new = h.objs.size();
         return h;
@@ -424,7 +436,7 @@ public:
     void load_default_skybox() { skybox.reset(); }
     void load_spherical_skybox(std::shared_ptr<RTWImage> im) { skybox = im; }
     void add_element(Hittables e, const std::string& alias) {   // scene/mod.rs:159-188
-        if (e.kind == CR_PRIM_LIST) { elements.push_back(std::move(e)); return; }   // :164-166: kept as it is, the alias is not registered
+        if (e.kind == CR_PRIM_LIST || e.kind == CR_PRIM_BVH) { elements.push_back(std::move(e)); return; }   // :161-166: kept as it is, the alias is not registered
         e.id = vend_id(alias, e.kind == CR_PRIM_SPHERE ? "Sphere" : "Triangle");
         elements.push_back(std::move(e));
     }
@@ -512,7 +524,12 @@ public:
             f.keys.insert(f.keys.end(), ks.begin(), ks.end());
         };
         for (const Hittables& e : elements) {
-            if (e.kind == CR_PRIM_LIST) {   // the list record, then its objects (crucible_hip.h CR_PRIM_LIST)
+            if (e.kind == CR_PRIM_BVH) {   // the wrapper record, then its objects (crucible_hip.h CR_PRIM_BVH)
+                CrPrimitive p{CR_PRIM_BVH, 0, 0, 0, 0, 0, {0}};
+                p.v[0] = (double)(f.prims.size() + 1); p.v[1] = (double)e.objs.size();
+                f.prims.push_back(p);
+                for (const Hittables& o : e.objs) emit(o, CR_PRIM_MEMBER);
+            } else if (e.kind == CR_PRIM_LIST) {   // the list record, then its objects (crucible_hip.h CR_PRIM_LIST)
                 std::vector<const Hittables*> objs;
                 bool empty_box = false;
                 e.spliced(objs, &empty_box);
@@ -772,6 +789,9 @@ inline Scene teapot_as_list(size_t threads, uint32_t image_width = 400, uint32_t
     outer.add(inner);
     sc.add_element(std::move(outer), "outer");
     sc.add_element(Hittables::hit_list(), "nothing");
+    // ... and a pre-built BVHWrapper as an element (scene/mod.rs:161-163)
+    sc.add_element(Hittables::bvh_wrapper(Hittables::hit_list({Hittables::sphere(Point3{1.5, 0.3, 3.0}, 0.3, matte), Hittables::sphere(Point3{0.6, 0.3, 3.4}, 0.3, glass),
+                                                                Hittables::sphere(Point3{-0.4, 0.3, 3.6}, 0.3, matte)})), "wrapped");
     return sc;
 }
 

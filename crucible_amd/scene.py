@@ -277,6 +277,27 @@ class HitList:
         raise ValueError("this HitList's box is neither Aabb::default() nor the union of its objects: not representable")
 
 
+class BVHWrapper:
+    """objects/bvhwrapper.rs as a scene element (scene/mod.rs:161-163): `BVHWrapper.new_wrapper(list)` keeps the list's
+    visible spheres and triangles (bvhwrapper.rs:16-26) -- the library rebuilds the tree from them with the reference's
+    own algorithm -- and answers an empty HitList when there is none (:28-30).  Lists or wrappers inside the list are
+    not representable."""
+
+    def __init__(self, objs):
+        self.id, self.hide, self.timeline = -1, False, None
+        self.objs = objs
+
+    @classmethod
+    def new_wrapper(cls, lst):
+        objs = []
+        for o in (lst.get_objs() if isinstance(lst, HitList) else lst):
+            if not isinstance(o, (Sphere, Triangle)):
+                raise ValueError("a BVHWrapper element may hold spheres and triangles only")
+            if not o.hide:
+                objs.append(o)
+        return cls(objs) if objs else HitList.default()
+
+
 def build_asset_path(asset_filename):
     """asset_loader/mod.rs:6-41: $ASSET_DIR is prepended verbatim; else `assets/` up to six levels up."""
     folder = os.environ.get("ASSET_DIR")
@@ -455,7 +476,7 @@ class Scene:
         self.skybox = file if isinstance(file, RTWImage) else RTWImage.new(file)
 
     def add_element(self, element, alias):
-        if isinstance(element, HitList):   # scene/mod.rs:164-166: added as it is, the alias is not registered
+        if isinstance(element, (HitList, BVHWrapper)):   # scene/mod.rs:161-166: added as it is, the alias is not registered
             self.elements.append(element)
             return
         element.id = self._vend_id(alias, "Sphere" if isinstance(element, Sphere) else "Triangle")
@@ -581,7 +602,13 @@ class Scene:
             keys.extend(ks)
 
         for e in self.elements:
-            if isinstance(e, HitList):   # the list record, then its objects (include/crucible_hip.h CR_PRIM_LIST)
+            if isinstance(e, BVHWrapper):   # the wrapper record, then its objects (include/crucible_hip.h CR_PRIM_BVH)
+                v = (C.c_double * 9)()
+                v[0:2] = [len(prims) + 1, len(e.objs)]
+                prims.append(A.CrPrimitive(A.CR_PRIM_BVH, 0, 0, 0, 0, 0, v))
+                for o in e.objs:
+                    emit(o, A.CR_PRIM_MEMBER)
+            elif isinstance(e, HitList):   # the list record, then its objects (include/crucible_hip.h CR_PRIM_LIST)
                 objs, empty_box = e.spliced()
                 v = (C.c_double * 9)()
                 v[0:2] = [len(prims) + 1, len(objs)]

@@ -59,7 +59,7 @@ enum {
 enum { CR_REAL_F32 = 0, CR_REAL_F64 = 1 };
 
 /* ---- scene elements: Hittables::{Sphere,Triangle,HitList} (src/objects/mod.rs:109-115) ---- */
-enum { CR_PRIM_SPHERE = 0, CR_PRIM_TRIANGLE = 1, CR_PRIM_LIST = 2 };
+enum { CR_PRIM_SPHERE = 0, CR_PRIM_TRIANGLE = 1, CR_PRIM_LIST = 2, CR_PRIM_BVH = 3 };
 enum {
     CR_PRIM_HIDDEN = 1,      /* Sphere.hide / Triangle.hide (sphere.rs:18, triangle.rs:11)                       */
     CR_PRIM_MEMBER = 2,      /* this sphere/triangle is an object of a CR_PRIM_LIST record, not a scene element  */
@@ -81,9 +81,17 @@ enum {
  *              (HitList::hit, hitlist.rs:51-65); hidden objects return no hit (sphere.rs:62, triangle.rs:87)
  *              but still count towards an add()-built box.  A list inside a list behaves exactly like its
  *              objects spliced in place (the inner box is never read), which is how the host mirrors pass it;
- *              a BVHWrapper as a scene element is not representable (CR_ERR_UNSUPPORTED at the mirrors).
+ *   bvh      : a BVHWrapper handed to Scene::add_element (scene/mod.rs:161-163), i.e. the result of
+ *              BVHWrapper::new_wrapper(list) (bvhwrapper.rs:15-32): v[0], v[1] name its objects like a list's (spheres
+ *              and triangles flagged CR_PRIM_MEMBER; hidden ones are dropped, as new_wrapper drops them).  The library
+ *              rebuilds the inner tree with the reference's own algorithm (it is a function of the object list), the
+ *              outer build sorts the wrapper by its root box, and BVHWrapper::hit walks into it as into any wrapper.
+ *              cr_export_bvh answers CR_ERR_UNSUPPORTED for such a scene in CR_BVH_REFERENCE mode (a wrapper holding
+ *              one primitive and one sub-tree has no two-children form in the exported layout).  A wrapper without
+ *              a visible object is the empty list new_wrapper returns (bvhwrapper.rs:28-30).  Lists or wrappers
+ *              inside a wrapper are not representable (CR_ERR_UNSUPPORTED at the mirrors).
  *              Under the opt-in CR_BVH_SAH / _ORDERED / LBVH trees a list's visible objects are ordinary
- *              primitives of the tree.  material, key_first, key_count are unused for a list.
+ *              primitives of the tree (a bvh record's likewise).  material, key_first, key_count are unused for both.
  * key_first/key_count select this primitive's keyframes in CrSceneDesc.keys
  * (0 keys = static; the initial transform is the v[] values themselves).
  */

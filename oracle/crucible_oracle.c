@@ -719,6 +719,11 @@ static int bvh_hit(Hittable* b, const Ray* r, Interval ray_t, HitRecord* rec, Co
     if (!aabb_hit(&b->bbox, r, ray_t)) return 0;
     if (g_faithful) { dead_update_bb(b->left, r->tm); dead_update_bb(b->right, r->tm); }
     HitRecord hl, hr;
+    /* A BVHWrapper element (CR_PRIM_BVH) under a leaf wrapper.  The device stores the wrapper's other child -- a primitive
+     * or list, which the reference tests without any box -- as a record of its own with an empty box, and a span-1
+     * wrapper's second copy of the element as an empty record: one more record visited in either case. */
+    const int lb = b->left->kind == H_BVH, rb = b->right->kind == H_BVH;
+    if (lb != rb || (lb && b->left == b->right)) cn->node_tests++;
     Hittable *first = b->left, *second = b->right;
     if (b->near_axis) {
         const real d = b->near_axis == 1 ? r->direction.x : (b->near_axis == 2 ? r->direction.y : r->direction.z);
@@ -727,9 +732,11 @@ static int bvh_hit(Hittable* b, const Ray* r, Interval ray_t, HitRecord* rec, Co
     int hit_left = hittable_hit(first, r, ray_t, &hl, cn);
     Interval right_t = {ray_t.min, hit_left ? hl.t : ray_t.max};
     /* a span-1 wrapper holds the same object twice; the reference tests it twice (a list: all its objects twice) */
-    const uint64_t dedup_before = cn->prim_tests_dedup;
+    const Counters before = *cn;
     int hit_right = hittable_hit(second, r, right_t, &hr, cn);
-    if (b->left == b->right && b->left->kind != H_BVH) cn->prim_tests_dedup = dedup_before;
+    if (b->left == b->right && b->left->kind != H_BVH) cn->prim_tests_dedup = before.prim_tests_dedup;
+    /* the same sub-tree walked a second time finds nothing closer (every t is outside the shrunk interval): counted once */
+    if (b->left == b->right && b->left->kind == H_BVH) *cn = before;
     if (hit_right) { *rec = hr; return 1; }
     if (hit_left) { *rec = hl; return 1; }
     return 0;
@@ -808,20 +815,23 @@ static void scene_build_world(Scene* sc) {
     Hittable** tmp = (Hittable**)malloc(sizeof(Hittable*) * (size_t)(sc->n_prims + 1));
     /* bvhwrapper.rs:16-26: hidden spheres and triangles are dropped, a HitList stays whatever it holds */
     for (int i = 0; i < sc->n_prims; i++)
-        if (!sc->prims[i].member && (sc->prims[i].kind == H_HITLIST || !sc->prims[i].hide)) vis[n_vis++] = &sc->prims[i];
+        if (!sc->prims[i].member && (sc->prims[i].kind == H_HITLIST || sc->prims[i].kind == H_BVH || !sc->prims[i].hide)) vis[n_vis++] = &sc->prims[i];
     if (n_vis == 0) {
         memset(&sc->empty_list, 0, sizeof sc->empty_list);
         sc->empty_list.kind = H_HITLIST;
         sc->world = &sc->empty_list;
     } else {
-        sc->pool_cap = 2 * n_vis + 4;
-        sc->pool = (Hittable*)malloc(sizeof(Hittable) * (size_t)sc->pool_cap);
-        sc->pool_used = 0;
+        if (!sc->pool) {
+            sc->pool_cap = 2 * n_vis + 4;
+            sc->pool = (Hittable*)malloc(sizeof(Hittable) * (size_t)sc->pool_cap);
+            sc->pool_used = 0;
+        }
         Hittable* root = bvh_generate(sc, vis, tmp, 0, n_vis);
         root->bbox = aabb_from_boxes(root->left->bbox, root->right->bbox);   /* new_from_vec :39 */
         sc->world = root;
         for (int i = 0; i < sc->pool_used; i++) sc->pool[i].bbox0 = sc->pool[i].bbox;
     }
+    for (int i = 0; i < sc->n_prims; i++) sc->prims[i].bbox0 = sc->prims[i].bbox;   /* BVHWrapper elements live here */
     free(vis); free(tmp);
 }
 
@@ -1104,7 +1114,7 @@ EXPORT Scene* oracle_scene_create(const CrSceneDesc* d) {
         Hittable* h = &sc->prims[i];
         h->mat = p->material; h->hide = (p->flags & CR_PRIM_HIDDEN) != 0;
         h->member = (p->flags & CR_PRIM_MEMBER) != 0;
-        if (p->kind == CR_PRIM_LIST) { h->kind = H_HITLIST; h->hide = 0; continue; }   /* second pass below */
+        if (p->kind == CR_PRIM_LIST || p->kind == CR_PRIM_BVH) { h->kind = H_HITLIST; h->hide = 0; continue; }   /* second pass below */
         h->tl.n_keys = p->key_count; h->tl.keys = sc->keys + p->key_first;
         if (p->kind == CR_PRIM_SPHERE) {
             h->kind = H_SPHERE;
@@ -1117,6 +1127,30 @@ EXPORT Scene* oracle_scene_create(const CrSceneDesc* d) {
             h->bbox = triangle_bbox(v3(h->tl.init[0], h->tl.init[1], h->tl.init[2]), v3(h->vb[0], h->vb[1], h->vb[2]),
                                     v3(h->vc[0], h->vc[1], h->vc[2]));
         }
+    }
+    for (int i = 0; i < d->n_prims; i++) {   /* BVHWrapper elements (crucible_hip.h CR_PRIM_BVH): BVHWrapper::new_wrapper over the objects */
+        const CrPrimitive* p = &d->prims[i];
+        if (p->kind != CR_PRIM_BVH) continue;
+        const int first = (int)p->v[0], count = (int)p->v[1];
+        if (!sc->pool) {
+            sc->pool_cap = 2 * d->n_prims + 8;
+            sc->pool = (Hittable*)malloc(sizeof(Hittable) * (size_t)sc->pool_cap);
+            sc->pool_used = 0;
+        }
+        Hittable** vis = (Hittable**)malloc(sizeof(Hittable*) * (size_t)(count + 1));
+        Hittable** tmp = (Hittable**)malloc(sizeof(Hittable*) * (size_t)(count + 1));
+        int n_vis = 0;
+        for (int k = 0; k < count; k++) if (!sc->prims[first + k].hide) vis[n_vis++] = &sc->prims[first + k];   /* bvhwrapper.rs:16-26 */
+        Hittable* h = &sc->prims[i];
+        if (n_vis == 0) { h->kind = H_HITLIST; h->n_objs = 0; h->objs = NULL; h->bbox = aabb_empty(); }   /* :28-30 */
+        else {
+            Hittable* root = bvh_generate(sc, vis, tmp, 0, n_vis);
+            root->bbox = aabb_from_boxes(root->left->bbox, root->right->bbox);   /* new_from_vec :39 */
+            int member = h->member;
+            *h = *root;            /* the element itself is the root wrapper */
+            h->member = member;
+        }
+        free(vis); free(tmp);
     }
     for (int i = 0; i < d->n_prims; i++) {   /* HitList elements (crucible_hip.h CR_PRIM_LIST) */
         const CrPrimitive* p = &d->prims[i];
@@ -1222,6 +1256,7 @@ static Aabb refit_rec(Hittable* h, real ta, real tb) {
 static void scene_prepare_boxes(Scene* sc, int refit, real ta, real tb) {
     if (sc->world->kind != H_BVH) return;
     for (int i = 0; i < sc->pool_used; i++) sc->pool[i].bbox = sc->pool[i].bbox0;
+    for (int i = 0; i < sc->n_prims; i++) if (sc->prims[i].kind == H_BVH) sc->prims[i].bbox = sc->prims[i].bbox0;
     if (refit) (void)refit_rec(sc->world, ta, tb);
 }
 
@@ -1497,7 +1532,7 @@ EXPORT void oracle_use_list(Scene* sc) {
     l->kind = H_HITLIST;
     l->objs = (Hittable**)malloc(sizeof(Hittable*) * (size_t)(sc->n_prims + 1));
     for (int i = 0; i < sc->n_prims; i++)   /* a list element's objects are in prims themselves */
-        if (sc->prims[i].kind != H_HITLIST && !sc->prims[i].hide) l->objs[l->n_objs++] = &sc->prims[i];
+        if (sc->prims[i].kind != H_HITLIST && sc->prims[i].kind != H_BVH && !sc->prims[i].hide) l->objs[l->n_objs++] = &sc->prims[i];
     sc->world = l;
 }
 

@@ -1,7 +1,7 @@
 """Small scenes used by the parity tests and by tests/golden/make_golden.py."""
 import numpy as np
 
-from crucible_amd.scene import (LERP, LOCAL, NERP, WORLD, CheckerTexture, Dielectric, HitList, ImageTexture, Lambertian,
+from crucible_amd.scene import (LERP, LOCAL, NERP, WORLD, BVHWrapper, CheckerTexture, Dielectric, HitList, ImageTexture, Lambertian,
                                 Metal, RTWImage, Scene, SolidColor, Sphere, Triangle)
 
 
@@ -221,4 +221,68 @@ def list_scene(width=96, samples=6, frame=0, depth=8, variant="mixed"):
     sc.add_element(outer, "outer")
     sc.add_element(single, "single")
     sc.add_element(pair, "pair")
+    return sc
+
+
+def wrapped_scene(width=96, samples=6, frame=0, depth=8, variant="mixed"):
+    """BVHWrapper elements (`scene.add_element(BVHWrapper::new_wrapper(list), ..)`, scene/mod.rs:161-163): the outer build
+    sorts a wrapper by its root box and a leaf wrapper that holds it walks into it (bvhwrapper.rs:96-126).
+    "mixed": wrappers beside spheres, a triangle and a list -- leaves holding (primitive, wrapper), (wrapper, list) ...;
+    "only": the world is one wrapper (a span-1 root: the reference walks it twice); "pair": two wrappers (a span-2 root
+    of two sub-trees); "small": wrappers of one and of two objects, one without a visible object (an empty list)."""
+    sc = Scene.new_image(16.0 / 9.0, width, 1, 360.0, 1)
+    cam = sc.scene_cam
+    cam.set_samples(samples)
+    cam.set_max_depth(depth)
+    cam.look_from((0.5, 3.0, 9.5))
+    cam.look_at((0.0, 0.8, 0.0))
+    cam.set_vfov(36.0)
+    cam.frame = frame
+    rs = np.random.RandomState(12)
+    mats = [Lambertian.new_from_color((0.8, 0.2, 0.2), 1.0), Metal.new((0.8, 0.8, 0.9), 0.05), Dielectric.new(1.5),
+            Lambertian.new_from_texture(CheckerTexture.new_from_color(0.4, (0.9, 0.9, 0.2), (0.2, 0.2, 0.2)), 1.0)]
+
+    def cluster(cx, cz, n, keyed=False, hidden=False):
+        objs = []
+        for k in range(n):
+            if k % 4 == 3:
+                c = np.array([cx + rs.uniform(-1, 1), rs.uniform(0.2, 1.0), cz + rs.uniform(-1, 1)])
+                o = Triangle.new(*(tuple(c + rs.uniform(-0.4, 0.4, 3)) for _ in range(3)), mats[k % 4])
+            else:
+                o = Sphere.new((cx + rs.uniform(-1.2, 1.2), rs.uniform(0.2, 0.9), cz + rs.uniform(-1.2, 1.2)), rs.uniform(0.15, 0.35), mats[k % 4])
+            if keyed and k == 1:
+                o.timeline.translate_point((0.0, 0.9, 0.0), 0.5, LERP, LOCAL)
+            if hidden and k == 2:
+                o.hide = True      # new_wrapper drops it
+            objs.append(o)
+        return objs
+    big = BVHWrapper.new_wrapper(HitList.new(cluster(-2.0, 0.5, 17, keyed=True, hidden=True)))
+    other = BVHWrapper.new_wrapper(HitList.new(cluster(2.5, -0.5, 9)))
+    if variant == "only":
+        sc.add_element(big, "big")
+        return sc
+    if variant == "pair":
+        sc.add_element(big, "big")
+        sc.add_element(other, "other")
+        return sc
+    ground = Lambertian.new_from_texture(CheckerTexture.new_from_color(0.8, (0.2, 0.3, 0.1), (0.9, 0.9, 0.9)), 1.0)
+    sc.add_element(Sphere.new((0.0, -100.0, 0.0), 100.0, ground), "ground")
+    if variant == "small":
+        sc.add_element(BVHWrapper.new_wrapper(HitList.new(cluster(-2.0, 1.0, 1))), "one")
+        sc.add_element(BVHWrapper.new_wrapper(HitList.new(cluster(1.5, 0.0, 2))), "two")
+        gone = cluster(0.0, 2.0, 3)
+        for o in gone:
+            o.hide = True
+        sc.add_element(BVHWrapper.new_wrapper(HitList.new(gone)), "none")
+        return sc
+    sc.add_element(big, "big")
+    sc.add_element(Sphere.new((0.0, 0.6, 2.5), 0.6, mats[2]), "glass")
+    sc.add_element(other, "other")
+    row = HitList.default()
+    for o in cluster(-0.5, -2.5, 5):
+        row.add(o)
+    sc.add_element(row, "row")
+    sc.add_element(Triangle.new((-5.0, 0.0, -3.0), (-2.5, 0.0, -3.2), (-3.8, 2.2, -3.1), mats[1]), "fin")
+    sc.add_element(BVHWrapper.new_wrapper(HitList.new(cluster(4.5, 2.0, 3))), "third")
+    sc.translate_point((0.0, 0.0, 1.0), 1.0, LERP, LOCAL, "glass")
     return sc

@@ -8,7 +8,7 @@ import pytest
 
 from crucible_amd import _abi as A
 from crucible_amd.renderer import CrucibleError
-from crucible_amd.scene import (LERP, LOCAL, NERP, WORLD, CheckerTexture, Dielectric, HitList, ImageTexture, Lambertian, Metal,
+from crucible_amd.scene import (LERP, LOCAL, NERP, WORLD, BVHWrapper, CheckerTexture, Dielectric, HitList, ImageTexture, Lambertian, Metal,
                                 RTWImage, Scene, SolidColor, Sphere, Triangle)
 
 pytestmark = pytest.mark.gpu
@@ -17,7 +17,7 @@ COUNTERS = ("segments", "node_tests", "prim_tests", "texel_fetches")
 REALS = [(A.CR_REAL_F64, "f64"), (A.CR_REAL_F32, "f32")]
 
 
-def random_scene(seed, lists=False):
+def random_scene(seed, lists=False, wrappers=False):
     rs = np.random.RandomState(seed)
     u = rs.uniform
     width = int(rs.choice([17, 32, 45, 64, 73]))
@@ -126,6 +126,21 @@ def random_scene(seed, lists=False):
                         inner.add(o)
                     l.add(inner)
             sc.add_element(l, f"list{li}")
+    if wrappers:   # BVHWrapper elements (tests/test_gpu_lists.py): wrappers of 0..8 objects, some hidden (dropped), some keyed
+        for wi in range(int(rs.randint(1, 4))):
+            objs = []
+            for k in range(int(rs.randint(0, 9))):
+                if rs.rand() < 0.6:
+                    o = Sphere.new((u(-4, 4), u(0.2, 2.0), u(-4, 3)), u(0.15, 0.9), material())
+                else:
+                    c = np.array([u(-4, 4), u(0.0, 2.0), u(-4, 3)])
+                    o = Triangle.new(*(tuple(c + u(-1.2, 1.2, 3)) for _ in range(3)), material())
+                o.hide = rs.rand() < 0.15
+                if rs.rand() < 0.3:
+                    key, interp = float(rs.choice([0.02, 0.5, 1.0, 1.7])), (LERP if rs.rand() < 0.6 else NERP)
+                    o.timeline.translate_point(tuple(u(-1.5, 1.5, 3)), key, interp, LOCAL)
+                objs.append(o)
+            sc.add_element(BVHWrapper.new_wrapper(HitList.new(objs)), f"wrap{wi}")
     if rs.rand() < 0.5:
         sc.load_spherical_skybox(RTWImage(rs.randint(40, 256, size=(8, 16, 3)).astype(np.uint8)))
     if rs.rand() < 0.4:
@@ -135,7 +150,7 @@ def random_scene(seed, lists=False):
     return sc
 
 
-def hostile_scene(seed, lists=False):
+def hostile_scene(seed, lists=False, wrappers=False):
     """Degenerate inputs on purpose: axis-aligned camera rays (zero direction components: Aabb::hit's compare/select
     form), coincident and zero-radius spheres (ties, empty boxes), axis-flat and zero-area triangles, huge and tiny
     coordinates, scatter_prob 0 / negative / > 1 (division by zero, complements: the NaN policy), fuzz 1, ior 1,
@@ -207,6 +222,10 @@ def hostile_scene(seed, lists=False):
                 l.add(e)
         sc.add_element(l, "l")
         elems = elems[cut:]
+    if wrappers and elems:
+        cut = max(1, len(elems) // 2)
+        sc.add_element(BVHWrapper.new_wrapper(HitList.new(elems[:cut])), "w")
+        elems = elems[cut:]
     for k, e in enumerate(elems):
         if rs.rand() < 0.1:
             e.hide = True
@@ -216,7 +235,7 @@ def hostile_scene(seed, lists=False):
     return sc
 
 
-def big_scene(seed, lists=False):
+def big_scene(seed, lists=False, wrappers=False):
     """Hundreds to tens of thousands of primitives: trees that do not fit in LDS (the top-levels window, the all-global
     kernels, the f32 entry point for more than 65 536 wrappers), long list elements, keyed primitives among static ones."""
     rs = np.random.RandomState(seed)
@@ -246,13 +265,17 @@ def big_scene(seed, lists=False):
             o = Triangle.new(*(tuple(c + u(-0.3, 0.3, 3)) for _ in range(3)), m)
         if rs.rand() < 0.01:
             o.timeline.translate_point(tuple(u(-0.5, 0.5, 3)), float(rs.choice([0.01, 0.5, 1.5])), LERP if rs.rand() < 0.5 else NERP, LOCAL)
-        if lists and rs.rand() < 0.3:
+        if (lists or wrappers) and rs.rand() < 0.3:
             o.hide = rs.rand() < 0.05
             members.append(o)
         else:
             sc.add_element(o, f"p{k}")
             if rs.rand() < 0.02:
                 sc.hide_element(f"p{k}")
+    if wrappers and members:
+        half = len(members) // 2
+        sc.add_element(BVHWrapper.new_wrapper(HitList.new(members[:half])), "w0")
+        members = members[half:]
     if lists:
         cuts = sorted(rs.randint(0, len(members) + 1, size=3))
         for li, (a, b) in enumerate(zip([0] + cuts, cuts + [len(members)])):
@@ -267,9 +290,9 @@ def big_scene(seed, lists=False):
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
-@pytest.mark.parametrize("seed", list(range(36)) + list(range(100, 124)))
+@pytest.mark.parametrize("seed", list(range(36)) + list(range(100, 124)) + list(range(200, 224)))
 def test_random_scene_bit_exact(renderer, oracles, rt, tag, seed):
-    sc = random_scene(1000 + seed, lists=seed >= 100)   # seeds from 100: with HitList elements
+    sc = random_scene(1000 + seed, lists=seed >= 100, wrappers=seed >= 200)   # seeds from 100: with HitList elements, from 200: and BVHWrapper elements
     variant = seed % 3
     if variant == 1:
         sc.scene_cam.refit_boxes = True

@@ -219,3 +219,78 @@ def test_descriptor_rules(renderer):
     for edit in (past_the_end, fractional, unflagged_object, orphan, shared, hidden_list, list_in_list):
         broken(edit)
     renderer.upload_scene(good)   # the handle still takes a good scene
+
+
+# ---- BVHWrapper elements (scene/mod.rs:161-163)
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+@pytest.mark.parametrize("refit", [False, True], ids=["stale-boxes", "refit"])
+@pytest.mark.parametrize("variant,frame", [("mixed", 0), ("mixed", 1), ("only", 0), ("pair", 0), ("pair", 1), ("small", 0)])
+def test_wrapper_elements_bit_exact(renderer, oracles, rt, tag, refit, variant, frame):
+    sc = scenes.wrapped_scene(96, 4, frame=frame, variant=variant)
+    img, st = render(renderer, sc, rt, refit=refit)
+    ref, rst = oracles[rt].render_image(sc, seed=SEED)
+    same(img, st, ref, rst)
+
+
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+@pytest.mark.parametrize("env", [{"CRUCIBLE_PIPELINE": "wavefront"}, {"CRUCIBLE_PIPELINE": "queue"}, {"CRUCIBLE_SAMPLE_GRANULAR": "0"},
+                                 {"CRUCIBLE_LDS_LIMIT": "0", "CRUCIBLE_LDS_TOP_KB": "0"}, {"CRUCIBLE_LDS_LIMIT": "0", "CRUCIBLE_LDS_TOP_KB": "1"}],
+                         ids=["wavefront", "queue", "pixel-granular", "global", "top-1KB"])
+def test_wrapper_elements_in_the_other_pipelines(oracles, monkeypatch, rt, tag, env):
+    from crucible_amd.renderer import Renderer
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    r = Renderer(0)
+    try:
+        sc = scenes.wrapped_scene(80, 3, frame=1)
+        img, st = render(r, sc, rt)
+        ref, rst = oracles[rt].render_image(sc, seed=SEED)
+        same(img, st, ref, rst)
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+@pytest.mark.parametrize("mode", [A.CR_BVH_SAH, A.CR_BVH_SAH_ORDERED, A.CR_BVH_LBVH], ids=["sah", "ordered", "lbvh"])
+def test_wrapper_elements_in_the_other_bvh_modes(renderer, oracles, rt, tag, mode):
+    """There the wrappers' visible objects are primitives of the one tree."""
+    sc = scenes.wrapped_scene(80, 3, frame=1)
+    img, st = render(renderer, sc, rt, mode=mode, refit=True)
+    tree = renderer.export_bvh(rt)
+    flat = sc.flatten()
+    named = sorted({~c for c in tree[1].ravel() if c < 0})
+    assert named == [i for i, p in enumerate(flat.prims) if p.kind in (A.CR_PRIM_SPHERE, A.CR_PRIM_TRIANGLE) and not (p.flags & A.CR_PRIM_HIDDEN)]
+    ref, rst = oracles[rt].render_image(sc, seed=SEED, tree=tree)
+    same(img, st, ref, rst)
+
+
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+def test_a_wrapper_is_its_objects_when_nothing_clips(renderer, oracles, rt, tag):
+    """Static objects: wrapped, listed or added one by one, the closest hits are the same; and the reference-mode tree of a
+    scene with a wrapper element cannot be exported (its records are not two-children wrappers)."""
+    from crucible_amd.scene import BVHWrapper
+
+    def build(how):
+        sc = Scene.new_image(16.0 / 9.0, 96, 1, 360.0, 1)
+        cam = sc.scene_cam
+        cam.set_samples(4)
+        cam.set_max_depth(6)
+        cam.look_from((0.0, 2.5, 8.0))
+        cam.look_at((0.0, 0.5, 0.0))
+        cam.set_vfov(40.0)
+        sc.add_element(Sphere.new((0.0, -100.0, 0.0), 100.0, Lambertian.new_from_color((0.5, 0.5, 0.5), 1.0)), "ground")
+        rs = np.random.RandomState(4)
+        objs = [Sphere.new((rs.uniform(-4, 4), 0.3, rs.uniform(-3, 3)), 0.3, Lambertian.new_from_color(tuple(rs.uniform(0.1, 0.9, 3)), 1.0))
+                for _ in range(24)]
+        if how == "flat":
+            for k, o in enumerate(objs):
+                sc.add_element(o, f"s{k}")
+        else:
+            sc.add_element(BVHWrapper.new_wrapper(HitList.new(objs)), "w")
+        return sc
+    flat, _ = render(renderer, build("flat"), rt)
+    wrapped, _ = render(renderer, build("wrapped"), rt)
+    assert np.array_equal(flat, wrapped)
+    with pytest.raises(CrucibleError) as e:
+        renderer.export_bvh(rt)
+    assert e.value.code == A.CR_ERR_UNSUPPORTED

@@ -9,7 +9,7 @@ import pytest
 import scenes
 from crucible_amd import _abi as A
 from crucible_amd.demo_builder import SceneRng, book1_end_scene, load_teapot, procedural_sky
-from crucible_amd.scene import (LERP, LOCAL, NERP, WORLD, Camera, CheckerTexture, HitList, Lambertian, Metal, Scene,
+from crucible_amd.scene import (LERP, LOCAL, NERP, WORLD, BVHWrapper, Camera, CheckerTexture, HitList, Lambertian, Metal, Scene,
                                 Sphere, Triangle, load_obj)
 from crucible_amd.timeline import TransformTimeline
 
@@ -325,3 +325,25 @@ def test_mirror_rejects_boxes_it_cannot_describe():
     fine = HitList.new([HitList.new([Triangle.new((0, 0, 0), (1, 0, 0), (0, 1, 0), m)]), Sphere.new((0, 0, 0), 1.0, m)])
     objs, empty = fine.spliced()
     assert empty and [type(o).__name__ for o in objs] == ["Triangle", "Sphere"]
+
+
+def test_bvh_wrapper_element_mirror():
+    """BVHWrapper::new_wrapper(list) as a scene element (bvhwrapper.rs:15-32): hidden objects are dropped, no visible object
+    gives the empty list, anything but spheres and triangles inside is refused; flatten() emits the record and its objects."""
+    m = Lambertian.new_from_color((0.5, 0.5, 0.5), 1.0)
+    a, b, c = Sphere.new((0, 0, 0), 1.0, m), Sphere.new((2, 0, 0), 1.0, m), Triangle.new((0, 0, 0), (1, 0, 0), (0, 1, 0), m)
+    b.hide = True
+    w = BVHWrapper.new_wrapper(HitList.new([a, b, c]))
+    assert isinstance(w, BVHWrapper) and w.objs == [a, c]
+    b2 = Sphere.new((2, 0, 0), 1.0, m)
+    b2.hide = True
+    assert isinstance(BVHWrapper.new_wrapper(HitList.new([b2])), HitList)
+    with pytest.raises(ValueError):
+        BVHWrapper.new_wrapper(HitList.new([a, HitList.default()]))
+    sc = Scene.new_image(1.0, 8, 24, 180.0, 1)
+    sc.add_element(w, "w")
+    sc.add_element(Sphere.new((5, 0, 0), 1.0, m), "s")
+    flat = sc.flatten()
+    kinds = [(p.kind, p.flags) for p in flat.prims]
+    assert kinds == [(A.CR_PRIM_BVH, 0), (A.CR_PRIM_SPHERE, A.CR_PRIM_MEMBER), (A.CR_PRIM_TRIANGLE, A.CR_PRIM_MEMBER), (A.CR_PRIM_SPHERE, 0)]
+    assert (flat.prims[0].v[0], flat.prims[0].v[1]) == (1.0, 2.0)

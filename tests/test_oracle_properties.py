@@ -9,7 +9,7 @@ import pytest
 import scenes
 from crucible_amd import _abi as A
 from crucible_amd.demo_builder import book1_end_scene
-from crucible_amd.scene import (CheckerTexture, Dielectric, HitList, ImageTexture, Lambertian, Metal, RTWImage, Scene, Sphere,
+from crucible_amd.scene import (BVHWrapper, CheckerTexture, Dielectric, HitList, ImageTexture, Lambertian, Metal, RTWImage, Scene, Sphere,
                                 Triangle)
 
 INF = float("inf")
@@ -499,3 +499,51 @@ def test_span_one_list_is_walked_twice_and_counted_once(o64):
     img, st = o64.render_image(sc, seed=4)
     visible = 4                                    # five spheres, one hidden
     assert st["prim_tests"] <= visible * st["node_tests"]
+
+
+@pytest.mark.parametrize("variant", ["mixed", "only", "pair", "small"])
+def test_wrapper_element_scene_refit_agrees_with_the_linear_list(o64, variant):
+    """BVHWrapper elements (scene/mod.rs:161-163): with refit_boxes every tree level -- the element's own included --
+    follows the keyed objects and the closest hits are the linear list's."""
+    sc = scenes.wrapped_scene(64, 3, frame=1, variant=variant)
+    truth, _ = o64.render_image(sc, seed=9, linear_list=True)
+    sc.scene_cam.refit_boxes = True
+    fitted, _ = o64.render_image(sc, seed=9)
+    assert (fitted == truth).all(axis=2).mean() >= 0.995
+
+
+def test_wrapper_element_random_rays_equal_brute_force(o):
+    """Static objects: a world holding wrapper elements returns the closest hit of a linear scan."""
+    rs = np.random.RandomState(33)
+    m = Lambertian.new_from_color((0.5, 0.5, 0.5), 1.0)
+    for trial in range(6):
+        sc = build([])
+        geo = []
+        for wi in range(rs.randint(1, 4)):
+            objs = []
+            for k in range(rs.randint(1, 12)):
+                c, r = rs.uniform(-4, 4, size=3), rs.uniform(0.1, 1.0)
+                objs.append(Sphere.new(c, r, m))
+                objs[-1].hide = rs.rand() < 0.15
+                if not objs[-1].hide:
+                    geo.append(("s", np.array([*c, r])))
+            sc.add_element(BVHWrapper.new_wrapper(HitList.new(objs)), f"w{wi}")
+            if rs.rand() < 0.6:
+                c, r = rs.uniform(-4, 4, size=3), rs.uniform(0.1, 1.0)
+                sc.add_element(Sphere.new(c, r, m), f"s{wi}"); geo.append(("s", np.array([*c, r])))
+        h = o.scene_create(sc.flatten())
+        try:
+            for _ in range(300):
+                orig, d = rs.uniform(-6, 6, size=3), rs.normal(size=3)
+                best = INF
+                for kind, g in geo:
+                    hit, r = sphere_hit(o, g, orig, d, 0.001, best)
+                    if hit:
+                        best = float(r[0])
+                out = np.zeros(10, dtype=o.np_real); mat = np.zeros(1, dtype=np.int32)
+                hit = o.lib.oracle_world_hit(h, o._p(o.arr(orig)), o._p(o.arr(d)), 0.0, 0.001, INF, o._p(out), mat.ctypes.data)
+                assert (hit == 1) == (best < INF)
+                if hit:
+                    assert float(out[0]) == best
+        finally:
+            o.scene_destroy(h)
