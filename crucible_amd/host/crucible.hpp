@@ -151,6 +151,9 @@ struct RTWImage {   // decoded RGB8 (img_loader.rs:17-55)
         std::string res = line();
         if (sscanf(res.c_str(), "%c%c %d %c%c %d", &sy, &ay, &H, &sx, &ax, &W) != 6 || ay != 'Y' || ax != 'X' || sx != '+' || W < 1 || H < 1)
             throw std::runtime_error("unsupported Radiance resolution line: " + res);
+        // every pixel takes at least one byte of the file (a run covers 127 at most, one scanline at a time): a header that
+        // promises more than the file can hold is refused before anything is allocated
+        if ((uint64_t)W * (uint64_t)H > (uint64_t)d.size() * 128u) throw std::runtime_error("truncated Radiance data");
         auto im = std::make_shared<RTWImage>();
         im->width = W; im->height = H; im->rgb8.resize((size_t)W * H * 3);
         std::vector<uint8_t> sl((size_t)W * 4);

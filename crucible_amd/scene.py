@@ -79,6 +79,14 @@ class RTWImage:
 
 
 def decode_radiance(data):
+    """See _decode_radiance; a file that ends early is a ValueError like every other malformed input."""
+    try:
+        return _decode_radiance(data)
+    except IndexError:
+        raise ValueError("truncated Radiance data") from None
+
+
+def _decode_radiance(data):
     """Radiance .hdr (RGBE) -> HxWx3 uint8 the way the reference keeps images (`image` crate
     decode, then `to_rgb8()`, img_loader.rs:24-28): float = mantissa * 2^(e - 136) (0 when e == 0), then
     round(clamp(x, 0, 1) * 255).  The crate is not vendored: parity unpinned.  Flat, new-style RLE and old-style
@@ -87,7 +95,9 @@ def decode_radiance(data):
 
     def line():
         nonlocal pos
-        end = data.index(b"\n", pos)
+        end = data.find(b"\n", pos)
+        if end < 0:
+            raise ValueError("truncated Radiance header")
         out = data[pos:end]
         pos = end + 1
         return out
@@ -99,8 +109,17 @@ def decode_radiance(data):
     res = line().split()
     if len(res) != 4 or res[0] not in (b"-Y", b"+Y") or res[2] != b"+X":
         raise ValueError(f"unsupported Radiance resolution line: {res}")
-    H, W = int(res[1]), int(res[3])
+    try:
+        H, W = int(res[1]), int(res[3])
+    except ValueError:
+        raise ValueError(f"unsupported Radiance resolution line: {res}") from None
+    if H < 1 or W < 1:
+        raise ValueError(f"unsupported Radiance resolution line: {res}")
+    if W * H > len(data) * 128:   # every pixel takes at least one byte of the file (a run covers 127 at most)
+        raise ValueError("truncated Radiance data")
+    data = data + bytes(8)         # reads past the end see zeros and fail the run checks below instead of raising IndexError
     buf = np.frombuffer(data, dtype=np.uint8)
+    n_real = len(data) - 8
     rgbe = np.zeros((H, W, 4), dtype=np.uint8)
     for row in range(H):
         if 8 <= W < 32768 and data[pos] == 2 and data[pos + 1] == 2 and ((data[pos + 2] << 8) | data[pos + 3]) == W:
@@ -138,6 +157,8 @@ def decode_radiance(data):
                     rgbe[row, x] = q
                     x += 1
                     shift = 0
+    if pos > n_real:
+        raise ValueError("truncated Radiance data")
     if res[0] == b"+Y":
         rgbe = rgbe[::-1]
     e = rgbe[..., 3].astype(np.int32)

@@ -175,3 +175,21 @@ def test_cli_group_path_renders_the_same_files(cli, tmp_path, monkeypatch, force
     assert names == sorted(os.listdir(os.path.join(mb, "artifacts"))) == ["image0.ppm", "image1.ppm", "image2.ppm"]
     for n in names:
         assert open(os.path.join(ma, "artifacts", n)).read() == open(os.path.join(mb, "artifacts", n)).read(), n
+
+
+def test_cli_refuses_malformed_radiance_files(cli, tmp_path):
+    """The C++ loader on truncated / corrupted / oversized-header files: the `panic:` exit (101) or a clean load, never a
+    signal and never an allocation of what the header promises."""
+    from test_host_logic import _rgbe_from_float, write_hdr
+    rs = np.random.RandomState(3)
+    hdr = str(tmp_path / "g.hdr")
+    write_hdr(hdr, _rgbe_from_float(rs.rand(8, 40, 3)), "rle", False)
+    good = open(hdr, "rb").read()
+    cases = [good[:20], good[:len(good) // 2], good.replace(b"-Y 8 +X 40", b"-Y 99999999 +X 99999999"), good.replace(b"-Y 8 +X 40", b"-Y 8 +X 0"),
+             good.replace(b"#?", b"??"), good + b"garbage"]
+    for k, data in enumerate(cases):
+        f = str(tmp_path / f"m{k}.hdr")
+        open(f, "wb").write(data)
+        r = subprocess.run([cli, "--world", "5", "--sky", f, "--dump-desc", str(tmp_path / "o.bin")], cwd=ROOT, capture_output=True)
+        assert r.returncode in (0, 101), (k, r.returncode, r.stderr[-200:])
+        assert b"bad_alloc" not in r.stderr

@@ -347,3 +347,37 @@ def test_bvh_wrapper_element_mirror():
     kinds = [(p.kind, p.flags) for p in flat.prims]
     assert kinds == [(A.CR_PRIM_BVH, 0), (A.CR_PRIM_SPHERE, A.CR_PRIM_MEMBER), (A.CR_PRIM_TRIANGLE, A.CR_PRIM_MEMBER), (A.CR_PRIM_SPHERE, 0)]
     assert (flat.prims[0].v[0], flat.prims[0].v[1]) == (1.0, 2.0)
+
+
+def test_malformed_radiance_files_are_value_errors(tmp_path, monkeypatch):
+    """Truncated files, corrupted headers and runs, sizes the file cannot hold: ValueError, never IndexError / MemoryError
+    (the C++ loader answers the same inputs with its `panic:` exit, tests/test_cpp_host.py)."""
+    from crucible_amd.scene import decode_radiance
+    rs = np.random.RandomState(2)
+    img = rs.rand(8, 40, 3)
+    good = {}
+    for mode in ("rle", "flat", "old"):
+        p = str(tmp_path / f"g_{mode}.hdr")
+        write_hdr(p, _rgbe_from_float(img), mode, False)
+        good[mode] = open(p, "rb").read()
+        assert decode_radiance(good[mode]).shape == (8, 40, 3)
+    for it in range(300):
+        b = bytearray(good[("rle", "flat", "old")[it % 3]])
+        k = it % 5
+        if k == 0:
+            b = b[:rs.randint(0, len(b))]
+        elif k == 1:
+            for _ in range(rs.randint(1, 8)):
+                b[rs.randint(0, len(b))] = rs.randint(0, 256)
+        elif k == 2:
+            for _ in range(rs.randint(1, 6)):
+                b[rs.randint(0, 60)] = rs.randint(0, 256)
+        elif k == 3:
+            b += bytes(rs.randint(0, 256, size=rs.randint(1, 50)).tolist())
+        else:
+            b = b.replace(b"-Y 8 +X 40", [b"-Y 99999999 +X 99999999", b"-Y -1 +X 40", b"-Y 8 +X 0", b"+X 40 -Y 8", b"-Y 8"][it % 25 // 5])
+        try:
+            out = decode_radiance(bytes(b))
+            assert out.dtype == np.uint8 and out.ndim == 3
+        except ValueError:
+            pass
