@@ -1,5 +1,5 @@
 """Seeded random scenes beyond the committed ones (tests/test_gpu_fuzz.py's generator), HIP library vs oracle: images and
-counters must be equal.  usage: fuzz_campaign.py FIRST_SEED COUNT [lists] [wrappers] [hostile|big]   -- prints one line per mismatch and a summary.
+counters must be equal.  usage: fuzz_campaign.py FIRST_SEED COUNT [lists] [wrappers] [hostile|big|camera]   -- prints one line per mismatch and a summary.
 Test infrastructure (it imports the oracle); not part of the product."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,6 +16,7 @@ lists = "lists" in sys.argv[3:]
 hostile = "hostile" in sys.argv[3:]
 big = "big" in sys.argv[3:]
 wrappers = "wrappers" in sys.argv[3:]
+camera = "camera" in sys.argv[3:]
 
 
 oracles = {A.CR_REAL_F64: Oracle(A.CR_REAL_F64), A.CR_REAL_F32: Oracle(A.CR_REAL_F32)}
@@ -23,7 +24,7 @@ r = Renderer(0)
 bad, nan_scenes, t0 = 0, 0, time.time()
 for seed in range(first, first + count):
     try:
-        sc = (big_scene if big else hostile_scene if hostile else random_scene)(seed, lists=lists, wrappers=wrappers)
+        sc = hostile_scene(seed, lists=lists, wrappers=wrappers, degenerate_camera=True) if camera else (big_scene if big else hostile_scene if hostile else random_scene)(seed, lists=lists, wrappers=wrappers)
     except ValueError as e:   # the mirror's own argument checks (negative radius, fuzz > 1, ...)
         continue
     variant = seed % 3
@@ -59,5 +60,5 @@ for seed in range(first, first + count):
             bad += 1; print(f"ERROR seed {seed} rt {rt}: {type(e).__name__}: {e}", flush=True)
     if (seed - first) % (10 if big else 100) == (9 if big else 99):
         print(f"... {seed - first + 1} scenes, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
-print(f"done: {count} scenes x 2 precisions from seed {first}{' with lists' if lists else ''}{' with wrappers' if wrappers else ''}{' hostile' if hostile else ''}{' big' if big else ''}: {bad} mismatches, {nan_scenes} NaN-policy renders, {time.time() - t0:.0f} s")
+print(f"done: {count} scenes x 2 precisions from seed {first}{' with lists' if lists else ''}{' with wrappers' if wrappers else ''}{' hostile' if hostile else ''}{' big' if big else ''}{' degenerate cameras' if camera else ''}: {bad} mismatches, {nan_scenes} NaN-policy renders, {time.time() - t0:.0f} s")
 r.close()

@@ -150,7 +150,7 @@ def random_scene(seed, lists=False, wrappers=False):
     return sc
 
 
-def hostile_scene(seed, lists=False, wrappers=False):
+def hostile_scene(seed, lists=False, wrappers=False, degenerate_camera=False):
     """Degenerate inputs on purpose: axis-aligned camera rays (zero direction components: Aabb::hit's compare/select
     form), coincident and zero-radius spheres (ties, empty boxes), axis-flat and zero-area triangles, huge and tiny
     coordinates, scatter_prob 0 / negative / > 1 (division by zero, complements: the NaN policy), fuzz 1, ior 1,
@@ -174,6 +174,17 @@ def hostile_scene(seed, lists=False, wrappers=False):
         cam.set_vfov(u(5, 120))
     cam.set_defocus_angle(float(rs.choice([0.0, 0.0, 1.0])))
     cam.set_focus_dist(5.0 * scale)
+    if degenerate_camera:   # no basis (look_from == look_at, or vup along the view), zero focus distance, half-turn field of view
+        k = seed % 4
+        if k == 0:
+            cam.look_at(cam.look_from_tl.start_pos)
+        elif k == 1:
+            cam.look_from((0.0, 5.0 * scale, 0.0))
+            cam.look_at((0.0, 0.0, 0.0))            # vup = +y is along the view direction
+        elif k == 2:
+            cam.set_focus_dist(0.0)
+        else:
+            cam.set_vfov(float(rs.choice([0.0, 180.0, 360.0])))
 
     def texture(depth):
         if depth == 0 or rs.rand() < 0.3:
@@ -317,13 +328,14 @@ def test_random_scene_bit_exact(renderer, oracles, rt, tag, seed):
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
-@pytest.mark.parametrize("seed", [300052, 309589, 400541] + list(range(300000, 300045)))
+@pytest.mark.parametrize("seed", [300052, 309589, 400541] + list(range(300000, 300045)) + list(range(1200000, 1200008)))
 def test_hostile_scene_bit_exact(renderer, oracles, rt, tag, seed):
     """Degenerate inputs (hostile_scene): the same equalities.  300052 / 309589: zero-length radius keys at the frame time
     under refit_boxes (0/0 at the key's own start -- the refit rule skips that sample); 400541: an opt-in tree over a
     scene whose only element is a list without visible objects.  scripts/fuzz_campaign.py runs tens of thousands more."""
     try:
-        sc = hostile_scene(seed, lists=seed >= 400000 or (seed < 300045 and seed % 2 == 1))
+        sc = hostile_scene(seed, lists=seed >= 400000 or (seed < 300045 and seed % 2 == 1), wrappers=seed >= 1200000,
+                           degenerate_camera=seed >= 1200000)   # from 1200000: no camera basis / zero focus distance / half-turn fov
     except ValueError:
         pytest.skip("the mirror's own argument checks reject this scene")
     variant = seed % 3
