@@ -501,3 +501,49 @@ def test_random_sample_shards_and_groups(renderer, oracles, monkeypatch, rt, tag
         assert np.array_equal(img, expect, equal_nan=True)
     finally:
         g.close()
+
+
+def test_independent_handles_render_concurrently(oracles):
+    """one handle = one caller thread at a time, independent handles may run concurrently.  Four host threads,
+    each with its own handle on the one device, each rendering its own stream of random scenes (f64 and f32 alternating)
+    while the others do the same: every frame equals the oracle's."""
+    import threading
+    from crucible_amd.renderer import Renderer
+    results, errors = {}, []
+
+    def work(tid):
+        try:
+            r = Renderer(0)
+            try:
+                for k in range(12):
+                    seed = 3000 + 100 * tid + k
+                    sc = random_scene(seed, lists=k % 2 == 1, wrappers=k % 3 == 2)
+                    rt = REALS[(tid + k) % 2][0]
+                    r.upload_scene(sc.flatten())
+                    try:
+                        img, st = r.render(sc.scene_cam, seed=seed, real_type=rt)
+                    except CrucibleError as e:
+                        if e.code != A.CR_ERR_NAN:
+                            raise
+                        img, st = None, None
+                    results[(tid, k)] = (seed, rt, k, img, st)
+            finally:
+                r.close()
+        except Exception as e:   # noqa: BLE001 -- reported by the main thread
+            errors.append((tid, repr(e)))
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert len(results) == 48
+    for (tid, k), (seed, rt, kk, img, st) in sorted(results.items()):
+        sc = random_scene(seed, lists=kk % 2 == 1, wrappers=kk % 3 == 2)
+        ref, rst = oracles[rt].render_image(sc, seed=seed)
+        if img is None:
+            assert rst["nan_pixels"] > 0
+            continue
+        assert np.array_equal(img, ref), (tid, k)
+        for c in COUNTERS:
+            assert st[c] == rst[c], (tid, k, c)
