@@ -82,6 +82,17 @@ int main(int argc, char** argv) {
     FILE* json = argc > 1 ? fopen(argv[1], "w") : nullptr;
     if (json) fprintf(json, "{\"device\": \"%s\", \"cus\": %d, \"tick\": \"__builtin_readcyclecounter (s_memtime)\", \"rows\": [", prop.gcnArchName, n_cus);
     bool first = true;
+    if (const char* only = getenv("CHASE_ONLY")) {   // "R,table_MiB,waves_per_simd": one configuration (for a counter pass)
+        int R = 0, mb = 0, w = 0;
+        if (sscanf(only, "%d,%d,%d", &R, &mb, &w) != 3) { fprintf(stderr, "CHASE_ONLY=R,table_MiB,waves_per_simd\n"); return 2; }
+        const size_t bytes = (size_t)mb << 20;
+        // per launch: n_cus workgroups x (256 * w) lanes x 2000 steps, one R-byte record each; 4 launches
+        printf("known bytes per launch: %.0f (lanes %d x steps 2000 x %d B)\n", (double)n_cus * 256 * w * 2000.0 * R, n_cus * 256 * w, R);
+        int rc = R == 16 ? run<16>("only", bytes, w, n_cus, json, true) : R == 32 ? run<32>("only", bytes, w, n_cus, json, true)
+               : R == 64 ? run<64>("only", bytes, w, n_cus, json, true) : run<96>("only", bytes, w, n_cus, json, true);
+        if (json) { fprintf(json, "]}\n"); fclose(json); }
+        return rc;
+    }
     struct T { const char* label; size_t bytes; } tables[] = {{"L1 16KB", 16u << 10}, {"L2 2MB", 2u << 20}, {"MALL 64MB", 64u << 20}, {"HBM 512MB", 512u << 20}};
     for (const T& t : tables)
         for (int w : {1, 2, 4}) {
