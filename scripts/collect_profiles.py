@@ -1,6 +1,5 @@
-"""Copy the round's measurement files from gpurun_out/r02p into profiles/ and refresh the measured values in
-DESIGN.md / README.md from them (run after scripts/r02_profiles.sh; the values sit between <!--KEY--> ... <!--/KEY-->
-markers in the documents themselves, so the step can be repeated)."""
+"""Copy the round's measurement files from gpurun_out/r02p into profiles/ (attaching the PMC entries to the bench lines the
+way bench.py does) and print the values DESIGN.md section 4 / README.md quote, for the documents to be updated from."""
 import csv, glob, json, os, re, shutil, subprocess, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -65,11 +64,4 @@ vals = {
     "PMC_C2": pm("book1_1920x1080_spp512_f64"), "PMC_C3": pm("teapot_1920x1080_spp1024_f64"), "PMC_C4": pm("million_3840x2160_spp256_f64"),
     "PMC_C2F32": pm("book1_1920x1080_spp512_f32"), "KT_MS": f"{kt_main:.1f}", "KT_FIN": f"{kt_fin:.2f}",
 }
-# The measured values sit in the documents between invisible markers, <!--KEY-->value<!--/KEY-->, and are refreshed in place.
-for doc in ("DESIGN.md", "README.md"):
-    path = os.path.join(root, doc)
-    text = open(path).read()
-    for k, v in vals.items():
-        text, n = re.subn(r"<!--" + k + r"-->.*?<!--/" + k + r"-->", lambda m: "<!--" + k + "-->" + v + "<!--/" + k + "-->", text)
-    open(path, "w").write(text)
 print(json.dumps(vals, indent=1))
