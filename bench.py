@@ -139,6 +139,11 @@ def cpu_baseline(scene, seed, target_s, faithful):
 
 
 def main():
+    # stdout carries exactly one line, the result: everything else this process or its libraries print (RCCL's version banner at
+    # communicator set-up, for one) goes to stderr.  fd 1 is pointed at stderr and the line is written to the saved descriptor.
+    result_fd = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -415,7 +420,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload != "million":
             rec["cpu_baseline"] = cpu_baseline(scene, seed, 14.0, False)
             rec["cpu_baseline_faithful"] = cpu_baseline(scene, seed, 10.0, True)
-        print(json.dumps(rec), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(rec) + "\n").encode())
 
     if r is not None:
         r.close()
