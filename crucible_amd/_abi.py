@@ -1,7 +1,7 @@
 """ctypes mirror of include/crucible_hip.h (the C ABI).  Plain data only."""
 import ctypes as C
 
-CR_ABI_VERSION = 2
+CR_ABI_VERSION = 3
 
 CR_OK, CR_ERR_INVALID_ARG, CR_ERR_NO_DEVICE, CR_ERR_HIP, CR_ERR_NO_SCENE, CR_ERR_IO, CR_ERR_NAN, CR_ERR_UNSUPPORTED = range(8)
 CR_REAL_F32, CR_REAL_F64 = 0, 1
@@ -14,6 +14,7 @@ CR_BVH_REFERENCE, CR_BVH_SAH, CR_BVH_SAH_ORDERED, CR_BVH_LBVH = 0, 1, 2, 3
 CR_KEY_TX, CR_KEY_TY, CR_KEY_TZ, CR_KEY_RADIUS, CR_KEY_SCALE_X, CR_KEY_SCALE_Y, CR_KEY_SCALE_Z = 0, 1, 2, 3, 4, 5, 6
 CR_MAX_CHECKER_DEPTH = 32
 CR_KEY_NERP, CR_KEY_LERP = 0, 1
+CR_SUM_DEFAULT, CR_SUM_REFERENCE_ORDER, CR_SUM_RELAXED = 0, 1, 2
 
 
 class CrPrimitive(C.Structure):
@@ -57,7 +58,7 @@ class CrRenderParams(C.Structure):
     _fields_ = [("samples", C.c_int32), ("sample_begin", C.c_int32), ("sample_count", C.c_int32),
                 ("max_depth", C.c_int32), ("seed", C.c_uint64), ("frame", C.c_int32), ("real_type", C.c_int32),
                 ("frame_rate", C.c_double), ("shutter_angle", C.c_double), ("output_sum", C.c_int32),
-                ("refit_boxes", C.c_int32)]
+                ("refit_boxes", C.c_int32), ("sum_order", C.c_int32), ("_reserved", C.c_int32)]
 
 
 class CrStats(C.Structure):

@@ -105,6 +105,8 @@ struct CrHandle {
     hipEvent_t cam_ev[kCamSlots] = {};
     int cam_next = 0, cam_pending_slot = -1;
     DevBuf sample_buf, sg_acc;   // sample-granular megakernel: per-sample colours of a batch, running sums between batches
+    DevBuf fx_acc;               // CR_SUM_RELAXED: per-pixel fixed-point sums (3 x u64 per pixel)
+    int default_sum_order = CR_SUM_RELAXED;   // what CR_SUM_DEFAULT means on this handle (CRUCIBLE_SUM_ORDER=reference|relaxed)
     // wavefront pipeline state (wavefront.hpp)
     DevBuf wf_job, wf_rng, wf_ray, wf_depth, wf_hit_t, wf_hit_prim, wf_chunk, wf_ctrl, wf_samples, wf_acc;
     uint32_t* wf_ring_host = nullptr;   // host-mapped ring the extend kernel reports its queue length into
@@ -863,15 +865,26 @@ template <typename real> void key_to_real(const CrKeyframe& k, Key<real>& o) {
     o.t0 = (real)k.t0; o.t1 = (real)k.t1; o.a = (real)k.a; o.b = (real)k.b; o.channel = k.channel; o.interp = k.interp;
 }
 
-template <typename real, int RES, bool ANIM, bool ORD = false, bool LATENCY = false, bool CAMK = false>
-int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, CrStats* stats) {
-    constexpr bool LDS = RES != RES_GLOBAL;
+template <typename real, int RES, bool ANIM, bool ORD = false, bool LATENCY = false, bool CAMK = false, bool RELAX = false>
+int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t scene_lds_bytes, CrStats* stats) {
+    constexpr bool LDS = RES != RES_GLOBAL || RELAX;
     static_assert(!LATENCY || RES == RES_TOP, "the 6-waves-per-SIMD entry point exists for RES_TOP only");
     KernelArgs<real> args = args_in;
-    void (*kern)(const KernelArgs<real>) = pathtrace_kernel<real, RES, ANIM, ORD, CAMK>;
-    if (LATENCY) kern = pathtrace_kernel_latency<real, ANIM, ORD, CAMK>;
+    void (*kern)(const KernelArgs<real>) = pathtrace_kernel<real, RES, ANIM, ORD, CAMK, RELAX>;
+    if (LATENCY) kern = pathtrace_kernel_latency<real, ANIM, ORD, CAMK, RELAX>;
     const int max_block = LATENCY ? LatencyBlock : MaxBlock<real>::value;
-    if (LDS) HIP_TRY(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    // The work tile (sample-granular hand-out): 2^lw x 2^lh pixels times 64 >> (lw + lh) consecutive samples; by default
+    // 4 x 4 x 4, wider tiles of fewer samples when fewer than 4 samples are rendered.
+    const int32_t n_samples = args.sample_end - args.sample_begin;
+    int tile_lw = h->sg_lw, tile_lh = h->sg_lh;
+    if (tile_lw < 0) { const int ns = n_samples >= 4 ? 4 : (n_samples >= 2 ? 2 : 1); tile_lw = ns == 4 ? 2 : 3; tile_lh = ns == 1 ? 3 : 2; }
+    // RELAX: the waves' accumulator slots follow the scene in LDS (2 x 384 B per wave for a 16-pixel tile); a tile too
+    // large for what the scene leaves free falls back to 16 pixels (the surplus sample slots of its groups stay empty)
+    const size_t fx_off = RES != RES_GLOBAL ? ((scene_lds_bytes + 15) & ~(size_t)15) : 0;
+    if (RELAX && fx_off + fx_lds_bytes(max_block, (uint32_t)(tile_lw + tile_lh)) > (size_t)160 * 1024) { tile_lw = 2; tile_lh = 2; }
+    auto lds_for = [&](int block) { return RELAX ? fx_off + fx_lds_bytes(block, (uint32_t)(tile_lw + tile_lh)) : scene_lds_bytes; };
+    args.fx_lds_off = (uint32_t)fx_off;
+    if (LDS) HIP_TRY(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_for(max_block)));
     // Workgroup size: the candidate that keeps the most waves resident per CU (a larger
     // workgroup shares one LDS copy of the scene among more waves); ties go to the larger.
     int block = 256, per_cu = 1, best_waves = 0;
@@ -879,9 +892,10 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
         if (cand > max_block) continue;
         if (h->block_override > 0 && cand != h->block_override && h->block_override <= max_block) continue;
         int n = 0;
-        HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, cand, LDS ? lds_bytes : 0));
+        HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, cand, LDS ? lds_for(cand) : 0));
         if (n * cand / 64 > best_waves) { best_waves = n * cand / 64; block = cand; per_cu = n; }
     }
+    const size_t lds_bytes = lds_for(block);
     if (best_waves == 0) return fail(h, CR_ERR_HIP, "kernel does not fit on a CU");
     if (h->blocks_per_cu_override > 0) per_cu = h->blocks_per_cu_override;
     // Sample-granular mode: batches of samples whose colours fit the buffer; each batch is one launch of the
@@ -889,11 +903,11 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
     const size_t npix = (size_t)args.cam.W * (size_t)args.cam.H;
     const int32_t s_begin = args.sample_begin, s_end = args.sample_end;
     int32_t batch = 0;
-    if (h->sample_granular && s_end > s_begin) {
+    if ((h->sample_granular || RELAX) && s_end > s_begin) {
         const size_t per_sample = npix * 3 * sizeof(real);
-        batch = (int32_t)std::min<size_t>((size_t)(s_end - s_begin), std::max<size_t>(1, h->sample_buf_limit / per_sample));
-        int lw = h->sg_lw, lh = h->sg_lh;
-        if (lw < 0) { const int ns = batch >= 4 ? 4 : (batch >= 2 ? 2 : 1); lw = ns == 4 ? 2 : 3; lh = ns == 1 ? 3 : 2; }
+        batch = (int32_t)std::min<size_t>((size_t)(s_end - s_begin), RELAX ? (size_t)INT32_MAX : std::max<size_t>(1, h->sample_buf_limit / per_sample));
+        int lw = tile_lw, lh = tile_lh;
+        if (!RELAX && h->sg_lw < 0) { const int ns = batch >= 4 ? 4 : (batch >= 2 ? 2 : 1); lw = ns == 4 ? 2 : 3; lh = ns == 1 ? 3 : 2; }   // by the batch, which the buffer may have cut
         const uint32_t ns = 64u >> (lw + lh);
         args.sg_lw = (uint32_t)lw; args.sg_lh = (uint32_t)lh;
         args.tiles_x = ((uint32_t)args.cam.W + (1u << lw) - 1) >> lw;
@@ -904,11 +918,16 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
         if (max_groups < 1) batch = 0;
         else batch = (int32_t)std::min<uint64_t>((uint64_t)batch, max_groups * ns);
         // the buffer holds one colour per work item of a batch: whole tiles and whole sample groups (edge padding included)
-        auto batch_bytes = [&](int32_t b) { return (size_t)tiles * ((size_t)(b + (int32_t)ns - 1) / ns) * 64u * 3u * sizeof(real); };
-        while (batch > (int32_t)ns && batch_bytes(batch) > std::max(h->sample_buf_limit, batch_bytes((int32_t)ns))) batch -= (int32_t)ns;
-        if (batch > 0 && h->sample_buf.ensure(batch_bytes(batch)) != hipSuccess) { (void)hipGetLastError(); batch = 0; }
-        if (batch > 0 && batch < s_end - s_begin && h->sg_acc.ensure(per_sample) != hipSuccess) { (void)hipGetLastError(); batch = 0; }
-        if (batch == 0) { args.tiles_x = args_in.tiles_x; args.tiles_y = args_in.tiles_y; }   // fall back: a lane owns a pixel
+        if constexpr (RELAX) {
+            if (batch <= 0) return fail(h, CR_ERR_UNSUPPORTED, "image too large for the 32-bit work counter");
+            HIP_TRY(h, h->fx_acc.ensure(npix * 3 * sizeof(unsigned long long)));
+        } else {
+            auto batch_bytes = [&](int32_t b) { return (size_t)tiles * ((size_t)(b + (int32_t)ns - 1) / ns) * 64u * 3u * sizeof(real); };
+            while (batch > (int32_t)ns && batch_bytes(batch) > std::max(h->sample_buf_limit, batch_bytes((int32_t)ns))) batch -= (int32_t)ns;
+            if (batch > 0 && h->sample_buf.ensure(batch_bytes(batch)) != hipSuccess) { (void)hipGetLastError(); batch = 0; }
+            if (batch > 0 && batch < s_end - s_begin && h->sg_acc.ensure(per_sample) != hipSuccess) { (void)hipGetLastError(); batch = 0; }
+            if (batch == 0) { args.tiles_x = args_in.tiles_x; args.tiles_y = args_in.tiles_y; }   // fall back: a lane owns a pixel
+        }
     }
     args.sg_on = batch > 0 ? 1u : 0u;
     const uint32_t ns = args.sg_on ? (64u >> (args.sg_lw + args.sg_lh)) : 1u;
@@ -920,9 +939,19 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
     if ((uint64_t)grid > need_blocks) grid = (uint32_t)need_blocks;
     if (grid < 1) grid = 1;
     args.n_threads = grid * (uint32_t)block;
-    size_t stack_bytes = (size_t)3 * (size_t)(args.max_depth > 0 ? args.max_depth : 1) * args.n_threads * sizeof(real);
-    HIP_TRY(h, h->att_stack.ensure(stack_bytes));
-    args.att_stack = (real*)h->att_stack.p;
+    if constexpr (!RELAX) {
+        size_t stack_bytes = (size_t)3 * (size_t)(args.max_depth > 0 ? args.max_depth : 1) * args.n_threads * sizeof(real);
+        HIP_TRY(h, h->att_stack.ensure(stack_bytes));
+        args.att_stack = (real*)h->att_stack.p;
+    } else {
+        // n * 2^S < 2^63 for the n samples a pixel receives in this render: S = 52 up to 2047 samples
+        int lg = 0;
+        while (((int64_t)(s_end - s_begin) >> (lg + 1)) > 0) lg++;
+        const int S = std::min(52, 62 - lg);
+        args.fx_scale = std::ldexp(1.0, S);
+        args.fx_acc = (unsigned long long*)h->fx_acc.p;
+        HIP_TRY(h, hipMemsetAsync(h->fx_acc.p, 0, npix * 3 * sizeof(unsigned long long), h->stream));
+    }
     HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 64 * sizeof(uint64_t), h->stream));
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     if (!args.sg_on) {
@@ -946,9 +975,16 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t lds_bytes, C
             HIP_TRY(h, hipMemsetAsync(h->work_counter.p, 0, 4, h->stream));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(block), LDS ? lds_bytes : 0, h->stream, args);
             HIP_TRY(h, hipGetLastError());
+            if constexpr (RELAX) continue;   // the sums stay in fx_acc until the last batch
             const size_t fin_threads = ((size_t)args.tiles_x * args.tiles_y) << (args.sg_lw + args.sg_lh);
             hipLaunchKernelGGL((sg_finalize_kernel<real>), dim3((unsigned)((fin_threads + 255) / 256)), dim3(256), 0, h->stream, args,
                                (real*)h->sg_acc.p, b1 - b0, b0 == s_begin ? 1 : 0, b1 == s_end ? 1 : 0);
+            HIP_TRY(h, hipGetLastError());
+        }
+        if constexpr (RELAX) {
+            const size_t n = npix * 3;
+            hipLaunchKernelGGL((fx_finalize_kernel<real>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream,
+                               (const unsigned long long*)h->fx_acc.p, args.out, n, 1.0 / args.fx_scale, (double)args.samples_total, args.output_sum);
             HIP_TRY(h, hipGetLastError());
         }
         args.sample_begin = s_begin; args.sample_end = s_end;
@@ -1176,6 +1212,20 @@ int32_t render_wavefront(CrHandle* h, const KernelArgs<real>& a, DevScene<real>&
     return anim ? wf_run<real, RES_GLOBAL, true>(h, W, 0, s_begin, s_count, bc, stats) : wf_run<real, RES_GLOBAL, false>(h, W, 0, s_begin, s_count, bc, stats);
 }
 
+// Picks the kernel variant: keyed primitives (ANIM), camera keys alone (CAMK) or neither, each in the reference's
+// summation order or with relaxed sums (CrRenderParams.sum_order).
+template <typename real, int RES, bool ORD, bool LATENCY>
+int32_t launch_variant(CrHandle* h, const KernelArgs<real>& a, size_t lds_bytes, CrStats* stats, bool anim, bool cam_keys, bool relax) {
+    if (relax) {
+        if (anim) return launch<real, RES, true, ORD, LATENCY, false, true>(h, a, lds_bytes, stats);
+        if (cam_keys) return launch<real, RES, false, ORD, LATENCY, true, true>(h, a, lds_bytes, stats);
+        return launch<real, RES, false, ORD, LATENCY, false, true>(h, a, lds_bytes, stats);
+    }
+    if (anim) return launch<real, RES, true, ORD, LATENCY, false, false>(h, a, lds_bytes, stats);
+    if (cam_keys) return launch<real, RES, false, ORD, LATENCY, true, false>(h, a, lds_bytes, stats);
+    return launch<real, RES, false, ORD, LATENCY, false, false>(h, a, lds_bytes, stats);
+}
+
 template <typename real>
 int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* p, void* d_out, CrStats* stats) {
     int32_t rc = build_dev_scene<real>(h);
@@ -1279,11 +1329,15 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     // the ANIM kernels also carry the decode of leaves that hold a HitList element (pathtrace.hpp walk_round)
     const bool anim = ds.animated || ds.has_leaf_runs;   // keyed primitives (the ANIM kernels also follow a keyed camera)
     const bool cam_keys = c.animated;                     // camera keys alone: the static kernels' CAMK variant
+    // relaxed sums exist in the megakernel; the alternative pipelines are reference-order cross-checks
+    const int sum_order = p->sum_order == CR_SUM_DEFAULT ? (h->pipeline == 0 ? h->default_sum_order : CR_SUM_REFERENCE_ORDER) : p->sum_order;
+    if (sum_order == CR_SUM_RELAXED && h->pipeline != 0) return fail(h, CR_ERR_UNSUPPORTED, "CR_SUM_RELAXED is implemented by the megakernel pipeline only");
+    const bool relax = sum_order == CR_SUM_RELAXED;
     if (ds.ordered) {   // near-child-first walk: megakernel only
         if (h->pipeline != 0) return fail(h, CR_ERR_UNSUPPORTED, "CR_BVH_SAH_ORDERED is implemented by the megakernel pipeline only");
         if (ds.n_entries > 0 && ds.lds_bytes <= h->lds_limit) {
             a.lds_entries = ds.n_entries;
-            return anim ? launch<real, RES_LDS, true, true, false>(h, a, ds.lds_bytes, stats) : (cam_keys ? launch<real, RES_LDS, false, true, false, true>(h, a, ds.lds_bytes, stats) : launch<real, RES_LDS, false, true, false>(h, a, ds.lds_bytes, stats));
+            return launch_variant<real, RES_LDS, true, false>(h, a, ds.lds_bytes, stats, anim, cam_keys, relax);
         }
         constexpr bool f32 = std::is_same<real, float>::value;   // the double kernel needs far more than 80 VGPRs: it halves there
         const bool latency = f32 && h->latency_entries > 0 && ds.n_entries > h->latency_entries;
@@ -1291,11 +1345,11 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
         if (top > 0) {
             a.lds_entries = top;
             const size_t bytes = (size_t)top * sizeof(EntryO<real>);
-            if constexpr (f32) if (latency) return anim ? launch<real, RES_TOP, true, true, true>(h, a, bytes, stats) : (cam_keys ? launch<real, RES_TOP, false, true, true, true>(h, a, bytes, stats) : launch<real, RES_TOP, false, true, true>(h, a, bytes, stats));
-            return anim ? launch<real, RES_TOP, true, true, false>(h, a, bytes, stats) : (cam_keys ? launch<real, RES_TOP, false, true, false, true>(h, a, bytes, stats) : launch<real, RES_TOP, false, true, false>(h, a, bytes, stats));
+            if constexpr (f32) if (latency) return launch_variant<real, RES_TOP, true, true>(h, a, bytes, stats, anim, cam_keys, relax);
+            return launch_variant<real, RES_TOP, true, false>(h, a, bytes, stats, anim, cam_keys, relax);
         }
         a.lds_entries = 0;
-        return anim ? launch<real, RES_GLOBAL, true, true, false>(h, a, 0, stats) : (cam_keys ? launch<real, RES_GLOBAL, false, true, false, true>(h, a, 0, stats) : launch<real, RES_GLOBAL, false, true, false>(h, a, 0, stats));
+        return launch_variant<real, RES_GLOBAL, true, false>(h, a, 0, stats, anim, cam_keys, relax);
     }
     if (h->pipeline == 1) return render_wavefront<real>(h, a, ds, anim || cam_keys, stats);
     if (h->pipeline == 2) {   // LDS-queue megakernel when scene + slot arrays fit in LDS, else the plain megakernel below
@@ -1313,7 +1367,7 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     }
     if (ds.n_entries > 0 && ds.lds_bytes <= h->lds_limit) {
         a.lds_entries = ds.n_entries;
-        return anim ? launch<real, RES_LDS, true, false, false>(h, a, ds.lds_bytes, stats) : (cam_keys ? launch<real, RES_LDS, false, false, false, true>(h, a, ds.lds_bytes, stats) : launch<real, RES_LDS, false, false, false>(h, a, ds.lds_bytes, stats));
+        return launch_variant<real, RES_LDS, false, false>(h, a, ds.lds_bytes, stats, anim, cam_keys, relax);
     }
     constexpr bool f32 = std::is_same<real, float>::value;   // the double kernel needs far more than 80 VGPRs: it halves there
     const bool latency = f32 && h->latency_entries > 0 && ds.n_entries > h->latency_entries;
@@ -1324,11 +1378,11 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
         // materials and textures ride along when they are small (the tree can be large with two materials)
         const size_t side = (((size_t)ds.n_mats * sizeof(Mat<real>) + 15) & ~(size_t)15) + (((size_t)ds.n_texs * sizeof(Tex<real>) + 15) & ~(size_t)15);
         if (side <= h->lds_side_limit) { a.lds_side = 1; bytes = ((bytes + 15) & ~(size_t)15) + side; }
-        if constexpr (f32) if (latency) return anim ? launch<real, RES_TOP, true, false, true>(h, a, bytes, stats) : (cam_keys ? launch<real, RES_TOP, false, false, true, true>(h, a, bytes, stats) : launch<real, RES_TOP, false, false, true>(h, a, bytes, stats));
-        return anim ? launch<real, RES_TOP, true, false, false>(h, a, bytes, stats) : (cam_keys ? launch<real, RES_TOP, false, false, false, true>(h, a, bytes, stats) : launch<real, RES_TOP, false, false, false>(h, a, bytes, stats));
+        if constexpr (f32) if (latency) return launch_variant<real, RES_TOP, false, true>(h, a, bytes, stats, anim, cam_keys, relax);
+        return launch_variant<real, RES_TOP, false, false>(h, a, bytes, stats, anim, cam_keys, relax);
     }
     a.lds_entries = 0;
-    return anim ? launch<real, RES_GLOBAL, true, false, false>(h, a, 0, stats) : (cam_keys ? launch<real, RES_GLOBAL, false, false, false, true>(h, a, 0, stats) : launch<real, RES_GLOBAL, false, false, false>(h, a, 0, stats));
+    return launch_variant<real, RES_GLOBAL, false, false>(h, a, 0, stats, anim, cam_keys, relax);
 }
 
 int32_t validate_render(CrHandle* h, const CrCameraDesc* cam, const CrRenderParams* p) {
@@ -1342,6 +1396,7 @@ int32_t validate_render(CrHandle* h, const CrCameraDesc* cam, const CrRenderPara
         return fail(h, CR_ERR_INVALID_ARG, "sample range outside [0, samples)");
     if (p->max_depth < 0) return fail(h, CR_ERR_INVALID_ARG, "max_depth must be >= 0");
     if (p->real_type != CR_REAL_F32 && p->real_type != CR_REAL_F64) return fail(h, CR_ERR_INVALID_ARG, "unknown real_type");
+    if (p->sum_order != CR_SUM_DEFAULT && p->sum_order != CR_SUM_REFERENCE_ORDER && p->sum_order != CR_SUM_RELAXED) return fail(h, CR_ERR_INVALID_ARG, "unknown sum_order");
     if (!(p->frame_rate > 0)) return fail(h, CR_ERR_INVALID_ARG, "frame_rate must be positive");
     if ((cam->from_key_count > 0 && !cam->from_keys) || (cam->at_key_count > 0 && !cam->at_keys) || cam->from_key_count < 0 || cam->at_key_count < 0)
         return fail(h, CR_ERR_INVALID_ARG, "camera keyframe array missing");
@@ -1438,6 +1493,7 @@ int32_t cr_create(int32_t device_id, CrHandle** out) {
     if ((e = h->counters.ensure(64 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
     if (const char* s = getenv("CRUCIBLE_LDS_LIMIT")) h->lds_limit = (size_t)atol(s);
     if (const char* s = getenv("CRUCIBLE_SAMPLE_GRANULAR")) h->sample_granular = atoi(s) != 0;
+    if (const char* s = getenv("CRUCIBLE_SUM_ORDER")) h->default_sum_order = strcmp(s, "reference") == 0 ? CR_SUM_REFERENCE_ORDER : CR_SUM_RELAXED;
     if (const char* s = getenv("CRUCIBLE_SAMPLE_BUF_MB")) h->sample_buf_limit = (size_t)std::max(0L, atol(s)) << 20;
     if (const char* s = getenv("CRUCIBLE_SG_CHUNK")) h->sg_chunk_override = std::max(0, atoi(s));
     if (const char* s = getenv("CRUCIBLE_SG_TILE")) {
@@ -1470,7 +1526,7 @@ void cr_destroy(CrHandle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->s32.release(); h->s64.release();
     h->images.release(); h->texels.release(); h->work_counter.release(); h->counters.release();
-    h->att_stack.release(); h->out_buf.release(); h->sample_buf.release(); h->sg_acc.release();
+    h->att_stack.release(); h->out_buf.release(); h->sample_buf.release(); h->sg_acc.release(); h->fx_acc.release();
     h->wf_job.release(); h->wf_rng.release(); h->wf_ray.release(); h->wf_depth.release(); h->wf_hit_t.release(); h->wf_hit_prim.release();
     h->wf_chunk.release(); h->wf_ctrl.release(); h->wf_samples.release(); h->wf_acc.release();
     for (int i = 0; i < CrHandle::kCamSlots; i++) {

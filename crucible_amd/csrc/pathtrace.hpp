@@ -251,7 +251,16 @@ template <typename real> struct KernelArgs {
     uint32_t walk_round_steps;  // wrappers a lane may step through before the wave intersects the parked leaves (speed only)
     uint32_t queue_walk_waves;  // queue_kernel: how many of the workgroup's 16 waves walk (the rest shade)
     uint32_t queue_min_batch, queue_patience;   // queue_kernel: shaders wait for this many hits, at most this many polls
+    // CR_SUM_RELAXED (the RELAX kernels): per-pixel fixed-point sums instead of per-sample colours.  A finished sample adds
+    // round(colour * fx_scale) to three 64-bit integers of its pixel -- integer adds commute, so the image does not
+    // depend on which wave finished which sample when.  Bit 63 of a sum is the NaN flag (a colour that is not a number).
+    unsigned long long* fx_acc;   // [H * W * 3], zeroed before the first launch of a render
+    double fx_scale;              // 2^S, S = 52 for up to 2047 samples per pixel
+    uint32_t fx_lds_off;          // byte offset of the waves' LDS accumulators: 2 slots per wave, each one work tile
+                                  // (2^(sg_lw + sg_lh) pixels x 3 channels) of 64-bit words
 };
+constexpr unsigned long long kFxNaN = 0x8000000000000000ull;
+constexpr size_t fx_lds_bytes(int block, uint32_t tile_log2) { return (size_t)(block / 64) * 2 * ((size_t)3 << tile_log2) * sizeof(unsigned long long); }
 
 // ------------------------------------------------------------------ timeline (timeline/mod.rs:233-263)
 // combine_and_compute = S * T * (0,0,0,1): T's last column is the initial position plus every active translate
@@ -688,10 +697,13 @@ template <typename T> CR_D T load_rec(const T* p, bool in_lds) {
 // outermost ray_color call returns), false when it scattered (ro/rd replaced, depth_left decremented).
 // The path's non-unit attenuations live at att_stack[(level * stack_stride + stack_slot) * 3 .. +2]: one record per
 // level, so a push is one contiguous store and an unwind step one contiguous load.
-template <typename real, bool ANIM, bool SIDE_SPLIT = false>
+// RELAX (CR_SUM_RELAXED): no stack -- *thr carries the product of the attenuations met so far (a_1 * a_2 * ... in path
+// order; the same multiplies as the reference's a_1 * (a_2 * (...)), associated the other way) and the colour handed
+// back is thr * sky.  Every factor is in [0, 1] or NaN, so Color's clamp (utils.rs:553-563) never changes a product.
+template <typename real, bool ANIM, bool SIDE_SPLIT = false, bool RELAX = false>
 CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<real>* mats, const Tex<real>* texs, V3<real>& ro, V3<real>& rd,
                 real rtime, uint64_t& rng, int32_t& depth_left, int32_t& stack_n, real best_t, int32_t best, uint32_t stack_stride,
-                uint32_t stack_slot, uint32_t& c_tex, V3<real>& col, Diag* dg = nullptr) {
+                uint32_t stack_slot, uint32_t& c_tex, V3<real>& col, Diag* dg = nullptr, V3<real>* thr = nullptr) {
     CR_DIAG_HIT(dg, DG_SHADE_WAVE, DG_SHADE_LANE);
     if (best >= 0) {
         CR_DIAG_HIT(dg, DG_HITSH_WAVE, DG_HITSH_LANE);
@@ -803,9 +815,12 @@ CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<re
         // factor and multiply on the way back (ray_casting.rs:128).  (1,1,1) multiplies exactly and
         // need not be stored.
         if (m.kind != 2) {
-            real* rec = A.att_stack + ((size_t)stack_n * stack_stride + stack_slot) * 3;
-            rec[0] = att.x; rec[1] = att.y; rec[2] = att.z;
-            stack_n++;
+            if constexpr (RELAX) { thr->x = thr->x * att.x; thr->y = thr->y * att.y; thr->z = thr->z * att.z; }
+            else {
+                real* rec = A.att_stack + ((size_t)stack_n * stack_stride + stack_slot) * 3;
+                rec[0] = att.x; rec[1] = att.y; rec[2] = att.z;
+                stack_n++;
+            }
         }
         ro = loc; rd = ndir; depth_left--;
         return false;
@@ -823,6 +838,7 @@ CR_D bool shade(const KernelArgs<real>& A, const Prim<real>* prims, const Mat<re
         real a = real(0.5) * (ud.y + real(1));
         col = c_add(c_scale(real(1) - a, mk<real>(1, 1, 1)), c_scale(a, mk<real>(real(0.5), real(0.7), real(1))));
     }
+    if constexpr (RELAX) { col = mk<real>(thr->x * col.x, thr->y * col.y, thr->z * col.z); return true; }
     // unwind: a_1 * (a_2 * ( ... (a_n * sky))).  The factors live in global memory; four levels are fetched
     // per round trip and applied innermost-first, so the product is formed in the reference's order.
     int32_t k = stack_n - 1;
@@ -1025,7 +1041,13 @@ template <typename real> struct MaxBlock { static constexpr int value = 1024; };
 // One lane = one pixel at a time, all of that pixel's samples in draw order (so the
 // per-pixel sum is the reference's sequential sum).  Lanes that finish a pixel pull the
 // next pixel index with one wave-aggregated atomic (ballot + prefix count).
-template <typename real, int RES, bool ANIM, bool ORD, bool CAMK = false>
+// RELAX: CR_SUM_RELAXED -- the same paths (same draws, same walks, same counters); a finished sample's colour is
+// thr * sky and goes into fixed-point per-pixel sums.  Each wave owns two LDS accumulators, one work tile (<= 16
+// pixels x 3 channels) each: ds_add_u64 there, and one global atomic per word when the wave moves on to another tile
+// -- about 48 global atomics per 1024 samples instead of 3 per sample (global atomics execute at the memory side, one
+// request per lane when the lanes' addresses are scattered).  A straggler whose tile has already been flushed adds to
+// the global sums directly.
+template <typename real, int RES, bool ANIM, bool ORD, bool CAMK = false, bool RELAX = false>
 CR_D void pathtrace_body(const KernelArgs<real>& A) {
     using EntryT = typename EntryOf<real, ORD>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1064,7 +1086,40 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t total_work = A.sg_on ? A.sg_total : A.tiles_x * A.tiles_y * 64u;
+    // RELAX: this wave's two accumulator slots and the tiles they hold (wave-uniform; kFxNoTile = empty)
+    constexpr uint32_t kFxNoTile = 0xffffffffu;
+    unsigned long long* fx_slots = nullptr;
+    uint32_t fx_tile0 = kFxNoTile, fx_tile1 = kFxNoTile, fx_mru = 0;
+    V3<real> thr = mk<real>(1, 1, 1);
+    const uint32_t fx_words = 3u << (A.sg_lw + A.sg_lh);   // words per slot
+    if constexpr (RELAX) {
+        fx_slots = (unsigned long long*)(smem + A.fx_lds_off) + (size_t)(threadIdx.x >> 6) * 2 * fx_words;
+        for (uint32_t k = lane; k < 2 * fx_words; k += 64) fx_slots[k] = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    // adds a slot's sums to the global ones and empties it (whole wave; `tile` is wave-uniform)
+    auto fx_flush = [&](uint32_t slot, uint32_t tile) {
+        if constexpr (RELAX) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (tile != kFxNoTile) {
+                const uint32_t ti = (tile % A.tiles_x) << A.sg_lw, tj = (tile / A.tiles_x) << A.sg_lh;
+                for (uint32_t k = lane; k < fx_words; k += 64) {   // 48 words for the usual 4 x 4 tile: one pass
+                    unsigned long long* w = fx_slots + slot * fx_words + k;
+                    const unsigned long long v = *w;
+                    if (v) {
+                        *w = 0ull;
+                        const uint32_t px = k / 3u, ch = k - px * 3u;
+                        const uint32_t pi = ti + (px & ((1u << A.sg_lw) - 1u)), pj = tj + (px >> A.sg_lw);
+                        unsigned long long* g = A.fx_acc + ((size_t)pj * (size_t)A.cam.W + pi) * 3 + ch;
+                        if (v & ~kFxNaN) atomicAdd(g, v & ~kFxNaN);
+                        if (v & kFxNaN) atomicOr(g, kFxNaN);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+    };
+    const uint32_t total_work = (A.sg_on || RELAX) ? A.sg_total : A.tiles_x * A.tiles_y * 64u;
     const CamConst<real>& cam = A.cam;
     // sample-granular mode: the wave's private slice [wv_next, wv_end) of the work counter (same value in all lanes)
     uint32_t wv_next = 0, wv_end = 0;
@@ -1095,7 +1150,7 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
         CR_DIAG_ONLY(if (CR_DIAG_LEADER()) dg_store.v[DG_OUTER_WAVE]++; d_t0 = __builtin_readcyclecounter();)
         // ---------------- regeneration: pixels
         uint64_t need = __ballot(state == ST_NEED_PIXEL);
-        if (need && A.sg_on) {
+        if (need && (A.sg_on || RELAX)) {
             // One (pixel, sample) per lane.  The wave takes SG_CHUNK consecutive items from the global counter at a
             // time and hands them to its lanes in order, so a wave stays on one tile's samples (coherent rays) and
             // the counter sees one atomic per 1024 samples.
@@ -1126,6 +1181,19 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
             }
             if (cnt > avail) { wv_next = fresh + (cnt - avail); wv_end = fresh + SG_CHUNK; }
             else wv_next += cnt;
+            if constexpr (RELAX) {
+                // make room for the tiles this round's new items belong to (consecutive items: one or two tiles)
+                const uint32_t my_tile = (pix_j >> A.sg_lh) * A.tiles_x + (pix_i >> A.sg_lw);
+                uint64_t fresh_items = __ballot(state == ST_NEED_SAMPLE) & need;
+                while (fresh_items) {
+                    const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)my_tile, __ffsll((unsigned long long)fresh_items) - 1);
+                    fresh_items &= ~__ballot(my_tile == t);
+                    if (t == fx_tile0) fx_mru = 0;
+                    else if (t == fx_tile1) fx_mru = 1;
+                    else if (fx_mru == 0) { fx_flush(1, fx_tile1); fx_tile1 = t; fx_mru = 1; }
+                    else { fx_flush(0, fx_tile0); fx_tile0 = t; fx_mru = 0; }
+                }
+            }
         } else if (need) {
             uint32_t cnt = (uint32_t)__popcll(need);
             uint32_t base = 0;
@@ -1153,6 +1221,7 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
             CR_DIAG_HIT(dgp, DG_REGEN_WAVE, DG_REGEN_LANE);
             camera_ray<real, ANIM, CAMK>(A, pix_i, pix_j, sample, rng, ro, rd, rtime);
             depth_left = A.max_depth; stack_n = 0;
+            if constexpr (RELAX) thr = mk<real>(1, 1, 1);
             state = ST_TRACE;
         }
 
@@ -1185,13 +1254,52 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
         CR_DIAG_ONLY({ unsigned long long t = __builtin_readcyclecounter(); d_t_trace += t - d_t0; d_t0 = t; })
         // ---------------- shade
         if (tracing) {
-            finished = shade<real, ANIM, RES == RES_TOP>(A, prims, mats, texs, ro, rd, rtime, rng, depth_left, stack_n, ws.best_t, ws.best,
-                                         A.n_threads, gtid, c_tex, col, dgp);
+            finished = shade<real, ANIM, RES == RES_TOP, RELAX>(A, prims, mats, texs, ro, rd, rtime, rng, depth_left, stack_n, ws.best_t, ws.best,
+                                         A.n_threads, gtid, c_tex, col, dgp, &thr);
             state = ST_TRACE;   // scattered: a fresh ray to walk (overwritten below when the path finished)
         }
 
         // ---------------- sample / pixel completion (average_samples, ray_casting.rs:154-173)
-        if (finished && A.sg_on) {   // the ordered sum happens in sg_finalize_kernel
+        if (RELAX && finished) {
+            if constexpr (RELAX) {
+                // round(c * 2^S) as an integer: c in [0, 1] (clamped Color), so c * 2^S + 2^52 lies in [2^52, 2^53], where
+                // doubles are the integers -- one fused multiply-add rounds once, and the integer is the difference of
+                // the bit patterns.  A colour that is not a number sets the pixel's NaN flag instead.
+                const bool black = col.x == real(0) && col.y == real(0) && col.z == real(0);   // adds nothing (depth ran out, scatter None)
+                if (!black) {
+                    const uint32_t tile = (pix_j >> A.sg_lh) * A.tiles_x + (pix_i >> A.sg_lw);
+                    const uint32_t px = ((pix_j & ((1u << A.sg_lh) - 1u)) << A.sg_lw) | (pix_i & ((1u << A.sg_lw) - 1u));
+                    const real cc[3] = {col.x, col.y, col.z};
+                    unsigned long long v[3];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const double x = (double)cc[c];
+                        v[c] = (x == x) ? (unsigned long long)(__builtin_bit_cast(long long, __builtin_fma(x, A.fx_scale, 0x1.0p52)) - 0x4330000000000000ll) : kFxNaN;
+                    }
+                    const bool nan = (v[0] | v[1] | v[2]) >> 63;
+                    unsigned long long* dst;
+                    bool in_lds = true;
+                    if (tile == fx_tile0) dst = fx_slots + px * 3u;
+                    else if (tile == fx_tile1) dst = fx_slots + fx_words + px * 3u;
+                    else { dst = A.fx_acc + ((size_t)pix_j * (size_t)cam.W + pix_i) * 3; in_lds = false; }
+                    if (!nan) {
+                        if (in_lds) {
+                            auto d = (__attribute__((address_space(3))) unsigned long long*)dst;   // ds_add_u64, not a flat atomic
+                            for (int c = 0; c < 3; c++) if (v[c]) (void)__hip_atomic_fetch_add(d + c, v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        } else {
+                            auto d = (__attribute__((address_space(1))) unsigned long long*)dst;
+                            for (int c = 0; c < 3; c++) if (v[c]) (void)__hip_atomic_fetch_add(d + c, v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    } else {
+                        for (int c = 0; c < 3; c++) {
+                            if (v[c] >> 63) atomicOr(dst + c, kFxNaN);
+                            else if (v[c]) atomicAdd(dst + c, v[c]);
+                        }
+                    }
+                }
+            }
+            state = ST_NEED_PIXEL;
+        } else if (finished && A.sg_on) {   // the ordered sum happens in sg_finalize_kernel
             real* o = A.sample_buf + (size_t)item * 3;
             o[0] = col.x; o[1] = col.y; o[2] = col.z;
             state = ST_NEED_PIXEL;
@@ -1211,6 +1319,7 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
         CR_DIAG_ONLY({ unsigned long long t = __builtin_readcyclecounter(); d_t_shade += t - d_t0; d_t0 = t; })
     }
 
+    if constexpr (RELAX) { fx_flush(0, fx_tile0); fx_flush(1, fx_tile1); }
     // flush work counters: one atomic per counter per wave
     auto wave_sum = [&](unsigned long long v) -> unsigned long long {
         unsigned long long s = v;
@@ -1235,9 +1344,9 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
 
     }
 }
-template <typename real, int RES, bool ANIM, bool ORD = false, bool CAMK = false>
+template <typename real, int RES, bool ANIM, bool ORD = false, bool CAMK = false, bool RELAX = false>
 __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const KernelArgs<real> A) {
-    pathtrace_body<real, RES, ANIM, ORD, CAMK>(A);
+    pathtrace_body<real, RES, ANIM, ORD, CAMK, RELAX>(A);
 }
 
 // The same kernel compiled for 6 waves per SIMD (<= 80 VGPRs, 512-thread groups), for trees far larger than the
@@ -1245,10 +1354,26 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const 
 // extra spills cost (1M spheres +11 %; the LDS-resident book1 and the 8K-wrapper teapot lose 3 % and stay on
 // pathtrace_kernel).  RES_TOP only.
 constexpr int LatencyBlock = 512;
-template <typename real, bool ANIM, bool ORD = false, bool CAMK = false>
+template <typename real, bool ANIM, bool ORD = false, bool CAMK = false, bool RELAX = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(64, LatencyBlock), amdgpu_waves_per_eu(6, 6)))
 pathtrace_kernel_latency(const KernelArgs<real> A) {
-    pathtrace_body<real, RES_TOP, ANIM, ORD, CAMK>(A);
+    pathtrace_body<real, RES_TOP, ANIM, ORD, CAMK, RELAX>(A);
+}
+
+// CR_SUM_RELAXED: the fixed-point sums become the frame -- sum * 2^-S, divided by the sample count unless the raw
+// sum of the shard is asked for; a set NaN flag gives NaN (the reference would have panicked in Color::new).
+template <typename real>
+__global__ void __launch_bounds__(256) fx_finalize_kernel(const unsigned long long* acc, real* out, size_t n, double inv_scale, double count,
+                                                          int32_t output_sum) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long v = acc[i];
+    const unsigned long long m = v & ~kFxNaN;
+    // exact u64 -> f64 in two halves (each below 2^53), then one rounding in the add
+    double s = ((double)(uint32_t)(m >> 32) * 4294967296.0 + (double)(uint32_t)m) * inv_scale;
+    if (!output_sum) s = s / count;
+    if (v & kFxNaN) s = __builtin_nan("");
+    out[i] = (real)s;
 }
 
 // average_samples' running sum (ray_casting.rs:161-165) for the sample-granular mode: the batch's colours are added

@@ -49,8 +49,11 @@ class Renderer:
     """One CrHandle (one HIP device).  Mirrors the call `Camera::render(&skybox, &world, fname)`
     (reference src/camera/mod.rs:270) split into upload_scene / render / write_ppm."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, sum_order=A.CR_SUM_DEFAULT):
         self.lib = load_library()
+        # CrRenderParams.sum_order of this renderer's renders unless a call names its own: CR_SUM_DEFAULT is the
+        # library's choice (relaxed), CR_SUM_REFERENCE_ORDER the parity mode the bit-exact tests run in
+        self.sum_order = sum_order
         h = C.c_void_p()
         rc = self.lib.cr_create(device, C.byref(h))
         if rc != A.CR_OK:
@@ -74,10 +77,10 @@ class Renderer:
         self._check(self.lib.cr_upload_scene(self.h, C.byref(flat.desc)))
 
     def render(self, cam, *, seed, real_type=A.CR_REAL_F32, sample_begin=0, sample_count=None, output_sum=False,
-               want_stats=True):
+               want_stats=True, sum_order=None):
         """Render into a host array (H, W, 3) of f32/f64.  Returns (image, stats dict)."""
         cd = cam.desc()
-        p = cam.params(seed, real_type, sample_begin, sample_count, output_sum)
+        p = cam.params(seed, real_type, sample_begin, sample_count, output_sum, self.sum_order if sum_order is None else sum_order)
         out = np.empty((cam.image_height, cam.image_width, 3), dtype=np_real(real_type))
         st = A.CrStats()
         self._check(self.lib.cr_render_host(self.h, C.byref(cd), C.byref(p), out.ctypes.data_as(C.c_void_p),
@@ -85,10 +88,10 @@ class Renderer:
         return out, st.as_dict()
 
     def render_device(self, cam, d_ptr, *, seed, real_type=A.CR_REAL_F32, sample_begin=0, sample_count=None,
-                      output_sum=False, want_stats=False):
+                      output_sum=False, want_stats=False, sum_order=None):
         """Render into device memory at `d_ptr` (W*H*3 reals).  Asynchronous unless want_stats."""
         cd = cam.desc()
-        p = cam.params(seed, real_type, sample_begin, sample_count, output_sum)
+        p = cam.params(seed, real_type, sample_begin, sample_count, output_sum, self.sum_order if sum_order is None else sum_order)
         st = A.CrStats()
         self._check(self.lib.cr_render_device(self.h, C.byref(cd), C.byref(p), C.c_void_p(d_ptr),
                                               C.byref(st) if want_stats else None))

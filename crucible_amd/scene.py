@@ -439,10 +439,11 @@ class Camera:
         d._keep = (fa, aa)
         return d
 
-    def params(self, seed, real_type, sample_begin=0, sample_count=None, output_sum=False):
+    def params(self, seed, real_type, sample_begin=0, sample_count=None, output_sum=False, sum_order=A.CR_SUM_DEFAULT):
         n = self.samples if sample_count is None else sample_count
         return A.CrRenderParams(self.samples, sample_begin, n, self.max_depth, seed, self.frame, real_type,
-                                self.frame_rate, self.shutter_angle, 1 if output_sum else 0, 1 if self.refit_boxes else 0)
+                                self.frame_rate, self.shutter_angle, 1 if output_sum else 0, 1 if self.refit_boxes else 0,
+                                sum_order, 0)
 
 
 # ------------------------------------------------------------------ scene

@@ -9,6 +9,12 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+# The suite's bit-exact tests run in the parity mode: CR_SUM_DEFAULT means the reference's summation order for every
+# handle created in this session (and in the CLI subprocesses the tests start).  tests/test_gpu_relaxed.py asks for
+# CR_SUM_RELAXED -- the library's own default -- explicitly.
+os.environ.setdefault("CRUCIBLE_SUM_ORDER", "reference")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -74,6 +74,20 @@ def test_book1_against_live_oracle(renderer, oracles, rt, tag):
 
 
 @pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
+def test_baseline_config0_book1_400x225_spp16(renderer, oracles, rt, tag):
+    """BASELINE configs[0]: the RTIOW book1 final scene at the reference's own demo size (demo_images.rs:14-26:
+    image_width 400 -> 400x225, depth 50) at 16 spp, whole frame against the live oracle: image bit for bit and the
+    four work counters."""
+    sc = book1_end_scene(1, scene_seed=1, image_width=400, samples=16)
+    sc.scene_cam.set_max_depth(50)
+    assert (sc.scene_cam.image_width, sc.scene_cam.image_height) == (400, 225)
+    img, st = gpu_render(renderer, sc, rt)
+    ref, rst = oracles[rt].render_image(sc, seed=SEED)
+    assert st["samples"] == 400 * 225 * 16
+    assert_exact(img, st, ref, rst)
+
+
+@pytest.mark.parametrize("rt,tag", REALS, ids=["f64", "f32"])
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 9])
 def test_bvh_edge_cases(renderer, oracles, rt, tag, n):
     """Empty world (HitList::default, bvhwrapper.rs:28-30), span-1 root, span-2 root, first sorted splits."""
