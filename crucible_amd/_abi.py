@@ -3,7 +3,7 @@ import ctypes as C
 
 CR_ABI_VERSION = 3
 
-CR_OK, CR_ERR_INVALID_ARG, CR_ERR_NO_DEVICE, CR_ERR_HIP, CR_ERR_NO_SCENE, CR_ERR_IO, CR_ERR_NAN, CR_ERR_UNSUPPORTED = range(8)
+CR_OK, CR_ERR_INVALID_ARG, CR_ERR_NO_DEVICE, CR_ERR_HIP, CR_ERR_NO_SCENE, CR_ERR_IO, CR_ERR_NAN, CR_ERR_UNSUPPORTED, CR_ERR_PEER = range(9)
 CR_REAL_F32, CR_REAL_F64 = 0, 1
 CR_PRIM_SPHERE, CR_PRIM_TRIANGLE, CR_PRIM_LIST, CR_PRIM_BVH = 0, 1, 2, 3
 CR_PRIM_HIDDEN, CR_PRIM_MEMBER, CR_LIST_EMPTY_BOX = 1, 2, 4

@@ -65,13 +65,14 @@ template <typename real> struct DevScene {
     bool has_lists = false;                  // the tree was built over at least one HitList element: its construction-time box
                                              // (empty, or grown over hidden objects too) is not what refit derives
     DevBuf entries_refit;                    // working copy whose boxes refit_level_kernel rewrites per frame
+    DevBuf screen, screen_refit;             // f64, unordered trees: the f32 screening records of entries / entries_refit
     bool ordered = false;                    // CR_BVH_SAH_ORDERED: `entries` holds EntryO records
     size_t entry_bytes = sizeof(Entry<real>);
     std::vector<int8_t> host_axis;           // ordered: split axis per wrapper (-1 leaf), same order as host_entries
     std::vector<int32_t> level_begin;        // entries of tree level l are [level_begin[l], level_begin[l+1])
     std::vector<Entry<real>> host_entries;   // the tree over the scene's objects (for cr_export_bvh); the device copy names primitive runs
     std::vector<int32_t> leaf_desc;          // leaf-order position -> index in the caller's primitive list
-    void release() { entries.release(); entries_refit.release(); leaf_runs.release(); prims.release(); mats.release(); texs.release(); keys.release(); built = false; }
+    void release() { entries.release(); entries_refit.release(); screen.release(); screen_refit.release(); leaf_runs.release(); prims.release(); mats.release(); texs.release(); keys.release(); built = false; }
 };
 
 }   // namespace
@@ -106,6 +107,8 @@ struct CrHandle {
     int cam_next = 0, cam_pending_slot = -1;
     DevBuf sample_buf, sg_acc;   // sample-granular megakernel: per-sample colours of a batch, running sums between batches
     DevBuf fx_acc;               // CR_SUM_RELAXED: per-pixel fixed-point sums (3 x u64 per pixel)
+    int screen_boxes = 1;        // f64, unordered trees: box tests decided on f32 screening records where f32 can (CRUCIBLE_SCREEN=0: never)
+    int screen_lds = 1;          // ... also for scenes that sit in LDS whole (CRUCIBLE_SCREEN_LDS=0: only trees read from global memory)
     int default_sum_order = CR_SUM_RELAXED;   // what CR_SUM_DEFAULT means on this handle (CRUCIBLE_SUM_ORDER=reference|relaxed)
     // wavefront pipeline state (wavefront.hpp)
     DevBuf wf_job, wf_rng, wf_ray, wf_depth, wf_hit_t, wf_hit_prim, wf_chunk, wf_ctrl, wf_samples, wf_acc;
@@ -850,6 +853,15 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
         HIP_TRY(h, hipMemcpyAsync(b.entries.data(), ds.entries.p, b.entries.size() * sizeof(Entry<real>), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
+    if constexpr (std::is_same<real, double>::value) {
+        if (!ds.ordered && ds.n_entries > 0) {   // the f32 screening records (pathtrace.hpp walk_round)
+            HIP_TRY(h, ds.screen.ensure((size_t)ds.n_entries * sizeof(ScreenEntry), entry_pad<ScreenEntry>()));
+            hipLaunchKernelGGL(screen_from_entries_kernel, dim3((unsigned)((ds.n_entries + 255) / 256)), dim3(256), 0, h->stream,
+                               (const Entry<double>*)ds.entries.p, (ScreenEntry*)ds.screen.p, ds.n_entries);
+            HIP_TRY(h, hipGetLastError());
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+        } else ds.screen.release();
+    }
     lap("uploads and boxes");
     ds.host_entries = b.entries;
     ds.host_axis = axis;
@@ -865,13 +877,13 @@ template <typename real> void key_to_real(const CrKeyframe& k, Key<real>& o) {
     o.t0 = (real)k.t0; o.t1 = (real)k.t1; o.a = (real)k.a; o.b = (real)k.b; o.channel = k.channel; o.interp = k.interp;
 }
 
-template <typename real, int RES, bool ANIM, bool ORD = false, bool LATENCY = false, bool CAMK = false, bool RELAX = false>
+template <typename real, int RES, bool ANIM, bool ORD = false, bool LATENCY = false, bool CAMK = false, bool RELAX = false, bool SCREEN = false>
 int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t scene_lds_bytes, CrStats* stats) {
     constexpr bool LDS = RES != RES_GLOBAL || RELAX;
     static_assert(!LATENCY || RES == RES_TOP, "the 6-waves-per-SIMD entry point exists for RES_TOP only");
     KernelArgs<real> args = args_in;
-    void (*kern)(const KernelArgs<real>) = pathtrace_kernel<real, RES, ANIM, ORD, CAMK, RELAX>;
-    if (LATENCY) kern = pathtrace_kernel_latency<real, ANIM, ORD, CAMK, RELAX>;
+    void (*kern)(const KernelArgs<real>) = pathtrace_kernel<real, RES, ANIM, ORD, CAMK, RELAX, SCREEN>;
+    if constexpr (LATENCY) kern = pathtrace_kernel_latency<real, ANIM, ORD, CAMK, RELAX>;
     const int max_block = LATENCY ? LatencyBlock : MaxBlock<real>::value;
     // The work tile (sample-granular hand-out): 2^lw x 2^lh pixels times 64 >> (lw + lh) consecutive samples; by default
     // 4 x 4 x 4, wider tiles of fewer samples when fewer than 4 samples are rendered.
@@ -1010,7 +1022,7 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t scene_lds_by
             HIP_TRY(h, hipMemcpy(d, h->counters.p, sizeof d, hipMemcpyDeviceToHost));
             const char* names[] = {"box_wave", "box_lane", "prim_wave", "prim_lane", "round_wave", "round_lane", "leafph_wave", "leafph_lane",
                                    "shade_wave", "shade_lane", "lamb_lane", "metal_lane", "diel_lane", "sky_lane", "ruv_wave", "ruv_lane",
-                                   "regen_wave", "regen_lane", "outer_wave", "unwind_wave", "unwind_lane", "hitsh_wave", "hitsh_lane"};
+                                   "regen_wave", "regen_lane", "outer_wave", "unwind_wave", "unwind_lane", "hitsh_wave", "hitsh_lane", "band_wave", "band_lane"};
             fprintf(stderr, "[diag] block=%d grid=%u clk_regen=%llu clk_trace=%llu clk_shade=%llu clk_total=%llu", block, grid,
                     (unsigned long long)d[9], (unsigned long long)d[10], (unsigned long long)d[11], (unsigned long long)d[12]);
             for (int i = 0; i < DG_N; i++) fprintf(stderr, " %s=%llu", names[i], (unsigned long long)d[16 + i]);
@@ -1214,16 +1226,16 @@ int32_t render_wavefront(CrHandle* h, const KernelArgs<real>& a, DevScene<real>&
 
 // Picks the kernel variant: keyed primitives (ANIM), camera keys alone (CAMK) or neither, each in the reference's
 // summation order or with relaxed sums (CrRenderParams.sum_order).
-template <typename real, int RES, bool ORD, bool LATENCY>
+template <typename real, int RES, bool ORD, bool LATENCY, bool SCREEN = false>
 int32_t launch_variant(CrHandle* h, const KernelArgs<real>& a, size_t lds_bytes, CrStats* stats, bool anim, bool cam_keys, bool relax) {
     if (relax) {
-        if (anim) return launch<real, RES, true, ORD, LATENCY, false, true>(h, a, lds_bytes, stats);
-        if (cam_keys) return launch<real, RES, false, ORD, LATENCY, true, true>(h, a, lds_bytes, stats);
-        return launch<real, RES, false, ORD, LATENCY, false, true>(h, a, lds_bytes, stats);
+        if (anim) return launch<real, RES, true, ORD, LATENCY, false, true, SCREEN>(h, a, lds_bytes, stats);
+        if (cam_keys) return launch<real, RES, false, ORD, LATENCY, true, true, SCREEN>(h, a, lds_bytes, stats);
+        return launch<real, RES, false, ORD, LATENCY, false, true, SCREEN>(h, a, lds_bytes, stats);
     }
-    if (anim) return launch<real, RES, true, ORD, LATENCY, false, false>(h, a, lds_bytes, stats);
-    if (cam_keys) return launch<real, RES, false, ORD, LATENCY, true, false>(h, a, lds_bytes, stats);
-    return launch<real, RES, false, ORD, LATENCY, false, false>(h, a, lds_bytes, stats);
+    if (anim) return launch<real, RES, true, ORD, LATENCY, false, false, SCREEN>(h, a, lds_bytes, stats);
+    if (cam_keys) return launch<real, RES, false, ORD, LATENCY, true, false, SCREEN>(h, a, lds_bytes, stats);
+    return launch<real, RES, false, ORD, LATENCY, false, false, SCREEN>(h, a, lds_bytes, stats);
 }
 
 template <typename real>
@@ -1284,10 +1296,19 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
         const int slot = h->cam_next;
         h->cam_next = (slot + 1) % CrHandle::kCamSlots;
         const size_t slot_bytes = CrHandle::kMaxCamKeys * sizeof(Key<double>);
-        if (!h->cam_host[slot]) {
-            HIP_TRY(h, hipHostMalloc(&h->cam_host[slot], slot_bytes, hipHostMallocDefault));
-            HIP_TRY(h, h->cam_dev[slot].ensure(slot_bytes));
-            HIP_TRY(h, hipEventCreateWithFlags(&h->cam_ev[slot], hipEventDisableTiming));
+        if (!h->cam_host[slot]) {   // the slot's three resources together, or none of them (a later render tries again)
+            void* host = nullptr;
+            hipEvent_t ev = nullptr;
+            hipError_t e = hipHostMalloc(&host, slot_bytes, hipHostMallocDefault);
+            if (e == hipSuccess) e = h->cam_dev[slot].ensure(slot_bytes);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e != hipSuccess) {
+                if (host) (void)hipHostFree(host);
+                h->cam_dev[slot].release();
+                (void)hipGetLastError();
+                return fail(h, CR_ERR_HIP, std::string("camera keyframe slot: ") + hipGetErrorString(e));
+            }
+            h->cam_host[slot] = host; h->cam_ev[slot] = ev;
         } else HIP_TRY(h, hipEventSynchronize(h->cam_ev[slot]));   // the slot's previous user has finished with it
         Key<real>* ck = (Key<real>*)h->cam_host[slot];
         for (int i = 0; i < cd->from_key_count; i++) key_to_real(cd->from_keys[i], ck[i]);
@@ -1317,6 +1338,22 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
         HIP_TRY(h, hipMemcpyAsync(ds.entries_refit.p, ds.entries.p, bytes, hipMemcpyDeviceToDevice, h->stream));
         { int32_t rc = run_box_kernels<real>(h, ds, ds.entries_refit.p, a.current_time, a.current_time + a.shutter_length, true); if (rc != CR_OK) return rc; }
         a.entries = (const Entry<real>*)ds.entries_refit.p;
+    }
+    // f64 megakernel on an unordered tree: the walk decides its box tests on the f32 screening records (half the bytes
+    // per step), see walk_round (A/B in profiles/experiments/r03_screen_ab.txt).
+    bool screen = false;
+    if constexpr (std::is_same<real, double>::value) {
+        screen = h->pipeline == 0 && !ds.ordered && ds.screen.p != nullptr && ds.n_entries > 0 && h->screen_boxes;
+        if (screen) {
+            a.screen = (const ScreenEntry*)ds.screen.p;
+            if (refit) {
+                HIP_TRY(h, ds.screen_refit.ensure((size_t)ds.n_entries * sizeof(ScreenEntry), ds.screen.pad));
+                hipLaunchKernelGGL(screen_from_entries_kernel, dim3((unsigned)((ds.n_entries + 255) / 256)), dim3(256), 0, h->stream,
+                                   (const Entry<double>*)ds.entries_refit.p, (ScreenEntry*)ds.screen_refit.p, ds.n_entries);
+                HIP_TRY(h, hipGetLastError());
+                a.screen = (const ScreenEntry*)ds.screen_refit.p;
+            }
+        }
     }
     a.tiles_x = (uint32_t)(c.W + 7) / 8u; a.tiles_y = (uint32_t)(c.H + 7) / 8u;
     a.work_counter = (uint32_t*)h->work_counter.p;
@@ -1367,21 +1404,32 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     }
     if (ds.n_entries > 0 && ds.lds_bytes <= h->lds_limit) {
         a.lds_entries = ds.n_entries;
+        if constexpr (std::is_same<real, double>::value) {   // screening records beside the scene, when both (and the relaxed sums' slots) fit
+            const size_t sb = ((size_t)ds.n_entries * sizeof(ScreenEntry) + 15) & ~(size_t)15;
+            if (screen && h->screen_lds && ds.lds_bytes + sb + fx_lds_bytes(MaxBlock<real>::value, 4) <= std::min(h->lds_limit, (size_t)160 * 1024))
+                return launch_variant<real, RES_LDS, false, false, true>(h, a, ds.lds_bytes + sb, stats, anim, cam_keys, relax);
+            a.screen = nullptr;
+        }
         return launch_variant<real, RES_LDS, false, false>(h, a, ds.lds_bytes, stats, anim, cam_keys, relax);
     }
     constexpr bool f32 = std::is_same<real, float>::value;   // the double kernel needs far more than 80 VGPRs: it halves there
     const bool latency = f32 && h->latency_entries > 0 && ds.n_entries > h->latency_entries;
-    const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, (latency ? h->latency_top_bytes : h->lds_top_bytes) / sizeof(Entry<real>));
+    const size_t window_rec = screen ? sizeof(ScreenEntry) : sizeof(Entry<real>);   // a window of screening records holds twice the wrappers
+    const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, (latency ? h->latency_top_bytes : h->lds_top_bytes) / window_rec);
     if (top > 0) {   // large scene: the top levels of the tree in LDS, everything else through L2
         a.lds_entries = top;
-        size_t bytes = (size_t)top * sizeof(Entry<real>);
+        size_t bytes = (size_t)top * window_rec;
         // materials and textures ride along when they are small (the tree can be large with two materials)
         const size_t side = (((size_t)ds.n_mats * sizeof(Mat<real>) + 15) & ~(size_t)15) + (((size_t)ds.n_texs * sizeof(Tex<real>) + 15) & ~(size_t)15);
-        if (side <= h->lds_side_limit) { a.lds_side = 1; bytes = ((bytes + 15) & ~(size_t)15) + side; }
+        // (the 6-waves-per-SIMD entry point runs three 512-thread groups per CU: window, side tables and the relaxed sums' slots of all three share 160 KB)
+        const size_t side_cap = latency ? (((size_t)160 * 1024 / 3 - 16 > bytes + fx_lds_bytes(LatencyBlock, 4)) ? (size_t)160 * 1024 / 3 - 16 - bytes - fx_lds_bytes(LatencyBlock, 4) : 0) : h->lds_side_limit;
+        if (side <= std::min(h->lds_side_limit, side_cap)) { a.lds_side = 1; bytes = ((bytes + 15) & ~(size_t)15) + side; }
         if constexpr (f32) if (latency) return launch_variant<real, RES_TOP, false, true>(h, a, bytes, stats, anim, cam_keys, relax);
+        if constexpr (!f32) if (screen) return launch_variant<real, RES_TOP, false, false, true>(h, a, bytes, stats, anim, cam_keys, relax);
         return launch_variant<real, RES_TOP, false, false>(h, a, bytes, stats, anim, cam_keys, relax);
     }
     a.lds_entries = 0;
+    if constexpr (!f32) if (screen) return launch_variant<real, RES_GLOBAL, false, false, true>(h, a, 0, stats, anim, cam_keys, relax);
     return launch_variant<real, RES_GLOBAL, false, false>(h, a, 0, stats, anim, cam_keys, relax);
 }
 
@@ -1493,6 +1541,8 @@ int32_t cr_create(int32_t device_id, CrHandle** out) {
     if ((e = h->counters.ensure(64 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
     if (const char* s = getenv("CRUCIBLE_LDS_LIMIT")) h->lds_limit = (size_t)atol(s);
     if (const char* s = getenv("CRUCIBLE_SAMPLE_GRANULAR")) h->sample_granular = atoi(s) != 0;
+    if (const char* s = getenv("CRUCIBLE_SCREEN")) h->screen_boxes = atoi(s) != 0;
+    if (const char* s = getenv("CRUCIBLE_SCREEN_LDS")) h->screen_lds = atoi(s) != 0;
     if (const char* s = getenv("CRUCIBLE_SUM_ORDER")) h->default_sum_order = strcmp(s, "reference") == 0 ? CR_SUM_REFERENCE_ORDER : CR_SUM_RELAXED;
     if (const char* s = getenv("CRUCIBLE_SAMPLE_BUF_MB")) h->sample_buf_limit = (size_t)std::max(0L, atol(s)) << 20;
     if (const char* s = getenv("CRUCIBLE_SG_CHUNK")) h->sg_chunk_override = std::max(0, atoi(s));
@@ -1760,13 +1810,26 @@ int32_t cr_write_ppm(const char* path, const void* rgb, int32_t real_type, int32
     if (!path || !rgb || w < 1 || hgt < 1 || (real_type != CR_REAL_F32 && real_type != CR_REAL_F64)) return CR_ERR_INVALID_ARG;
     FILE* f = fopen(path, "w");   // OpenOptions write+create+truncate, camera/mod.rs:275-279
     if (!f) return CR_ERR_IO;
-    std::vector<char> buf(1 << 20);
-    setvbuf(f, buf.data(), _IOFBF, buf.size());
+    // The text of `writeln!(file, "{color}")` per pixel (camera/mod.rs:306-311, utils.rs:422-437), formatted into memory
+    // rows at a time: 2 M fprintf calls per 1080p frame took 0.3 s, as long as the frame's render.
+    struct Dec { char s[4]; uint8_t n; };
+    static const std::vector<Dec> table = [] { std::vector<Dec> t(256); for (int v = 0; v < 256; v++) t[(size_t)v].n = (uint8_t)snprintf(t[(size_t)v].s, 4, "%d", v); return t; }();
     bool ok = fprintf(f, "P3\n%d %d\n255\n", w, hgt) > 0;   // camera/mod.rs:286
-    for (int64_t i = 0; ok && i < (int64_t)w * hgt; i++) {  // row-major, j outer (camera/mod.rs:306-311)
-        double c[3];
-        for (int k = 0; k < 3; k++) c[k] = real_type == CR_REAL_F64 ? ((const double*)rgb)[3 * i + k] : (double)((const float*)rgb)[3 * i + k];
-        ok = fprintf(f, "%u %u %u\n", display_byte(c[0]), display_byte(c[1]), display_byte(c[2])) > 0;
+    const int64_t npix = (int64_t)w * hgt, chunk = 1 << 16;
+    std::vector<char> buf((size_t)chunk * 36);   // three u32 of up to 10 digits, two blanks, a newline
+    for (int64_t p0 = 0; ok && p0 < npix; p0 += chunk) {   // row-major, j outer
+        char* o = buf.data();
+        const int64_t p1 = std::min(npix, p0 + chunk);
+        for (int64_t i = p0; i < p1; i++) {
+            for (int k = 0; k < 3; k++) {
+                const double c = real_type == CR_REAL_F64 ? ((const double*)rgb)[3 * i + k] : (double)((const float*)rgb)[3 * i + k];
+                const uint32_t v = display_byte(c);
+                if (v < 256u) { const Dec& d = table[v]; memcpy(o, d.s, 3); o += d.n; }
+                else o += snprintf(o, 11, "%u", v);   // a channel above 1: not a Color the reference could hold, printed as `as u32` would
+                *o++ = k == 2 ? '\n' : ' ';
+            }
+        }
+        ok = fwrite(buf.data(), 1, (size_t)(o - buf.data()), f) == (size_t)(o - buf.data());
     }
     ok = (fclose(f) == 0) && ok;
     return ok ? CR_OK : CR_ERR_IO;
@@ -1845,11 +1908,13 @@ int32_t cr_group_create(const int32_t* device_ids, int32_t n_devices, CrGroup** 
     const bool same_device = getenv("CRUCIBLE_GROUP_SAME_DEVICE") != nullptr;
     for (int i = 0; i < n_devices; i++) for (int j = 0; j < i; j++)
         if (device_ids[i] == device_ids[j] && !same_device) return gfail(nullptr, CR_ERR_INVALID_ARG, "a device appears twice in the list");
+    DeviceGuard guard;
     CrGroup* g = new CrGroup();
     g->same_device_sum = same_device && n_devices > 1;
     g->world = n_devices; g->first = 0;
     g->members.assign((size_t)n_devices, nullptr);
     g->partial.resize((size_t)n_devices);
+    g->status.resize((size_t)n_devices);
     for (int i = 0; i < n_devices; i++) {
         int32_t rc = cr_create(device_ids[i], &g->members[(size_t)i]);
         if (rc != CR_OK) { g_group_create_error = g_create_error; group_free(g); return rc; }
@@ -1885,10 +1950,12 @@ int32_t cr_group_create_rank(int32_t device_id, int32_t rank, int32_t world_size
     *out = nullptr;
     if (world_size < 1 || rank < 0 || rank >= world_size) return gfail(nullptr, CR_ERR_INVALID_ARG, "rank outside [0, world_size)");
     if (world_size > 1 && !id) return gfail(nullptr, CR_ERR_INVALID_ARG, "id is null");
+    DeviceGuard guard;
     CrGroup* g = new CrGroup();
     g->world = world_size; g->first = rank;
     g->members.assign(1, nullptr);
     g->partial.resize(1);
+    g->status.resize(1);
     int32_t rc = cr_create(device_id, &g->members[0]);
     if (rc != CR_OK) { g_group_create_error = g_create_error; group_free(g); return rc; }
     const bool force = getenv("CRUCIBLE_GROUP_FORCE_RCCL") != nullptr && id;
@@ -1908,7 +1975,7 @@ int32_t cr_group_create_rank(int32_t device_id, int32_t rank, int32_t world_size
     return CR_OK;
 }
 
-void cr_group_destroy(CrGroup* g) { group_free(g); }
+void cr_group_destroy(CrGroup* g) { DeviceGuard guard; group_free(g); }
 int32_t cr_group_local_size(CrGroup* g) { return g ? (int32_t)g->members.size() : 0; }
 int32_t cr_group_size(CrGroup* g) { return g ? g->world : 0; }
 int32_t cr_group_rank(CrGroup* g) { return g ? g->first : -1; }
@@ -1917,6 +1984,7 @@ const char* cr_group_last_error(CrGroup* g) { return g ? g->error.c_str() : g_gr
 
 int32_t cr_group_upload_scene(CrGroup* g, const CrSceneDesc* scene) {
     if (!g) return CR_ERR_INVALID_ARG;
+    DeviceGuard guard;
     for (CrHandle* h : g->members) {
         int32_t rc = cr_upload_scene(h, scene);
         if (rc != CR_OK) return gfail(g, rc, h->error);
@@ -1924,36 +1992,99 @@ int32_t cr_group_upload_scene(CrGroup* g, const CrSceneDesc* scene) {
     return CR_OK;
 }
 
-int32_t cr_group_render(CrGroup* g, const CrCameraDesc* cam, const CrRenderParams* params, void* d_out, CrGroupStats* stats) {
+// Failure handling.  Nothing is launched before every local member's arguments have been validated and its buffers exist,
+// so bad arguments fail the same way on every rank.  A member that fails later (its render, an allocation) does NOT leave:
+// with a collective, every member first takes part in a 4-byte ncclAllReduce(min) of "my render is fine" on the render's own
+// stream, and only a unanimous 1 goes on to the ncclReduce -- otherwise every rank returns an error (its own, or
+// CR_ERR_PEER) and the communicator is still consistent.  Only a failing collective call itself poisons the group
+// (its communicators are aborted; every later call answers CR_ERR_PEER): peers inside that collective cannot be told.
+// pre_rc / pre_msg: a failure this rank met before the call (cr_group_render_host's root-side buffer); it takes part
+// in the agreement like a failed render, so the other ranks are not left waiting.
+static int32_t group_render_impl(CrGroup* g, const CrCameraDesc* cam, const CrRenderParams* params, void* d_out, CrGroupStats* stats,
+                                 int32_t pre_rc, const char* pre_msg) {
     if (!g) return CR_ERR_INVALID_ARG;
-    if (!cam || !params) return gfail(g, CR_ERR_INVALID_ARG, "null camera or params");
+    if (g->poisoned) return gfail(g, CR_ERR_PEER, "an earlier collective of this group failed: destroy it and create a new one");
+    if (!cam || !params) return gfail(g, CR_ERR_INVALID_ARG, "null camera or params");   // the same on every rank
     const bool root_here = g->first == 0;
-    if (root_here && !d_out) return gfail(g, CR_ERR_INVALID_ARG, "the root member needs an output buffer");
-    const size_t n = (size_t)cam->image_width * (size_t)cam->image_height * 3;
-    const bool f64 = params->real_type == CR_REAL_F64;
-    const size_t bytes = n * (f64 ? sizeof(double) : sizeof(float));
+    DeviceGuard guard;   // the caller's current device is the caller's again on every way out
     const bool collective = !g->comms.empty();
+    const bool summed = g->world > 1 || collective;
     const int local = (int)g->members.size();
-    std::vector<int32_t> counts((size_t)local, 0);
-    // 1. every local member renders its shard, asynchronously on its own stream
+    std::vector<CrRenderParams> ps((size_t)local, *params);
+    // 0. arguments and buffers, before anything is launched
+    int32_t local_rc = CR_OK;
+    std::string local_err;
+    auto note = [&](int32_t rc, const std::string& msg) { if (local_rc == CR_OK && rc != CR_OK) { local_rc = rc; local_err = msg; } };
+    if (pre_rc != CR_OK) note(pre_rc, pre_msg ? pre_msg : "");
+    if (root_here && !d_out) note(CR_ERR_INVALID_ARG, "the root member needs an output buffer");
     for (int i = 0; i < local; i++) {
         CrHandle* h = g->members[(size_t)i];
-        CrRenderParams p = *params;
-        if (cr_group_shard(params->samples, g->first + i, g->world, &p.sample_begin, &p.sample_count) != CR_OK)
-            return gfail(g, CR_ERR_INVALID_ARG, "samples must be >= 0");
-        counts[(size_t)i] = p.sample_count;
-        void* dst = d_out;
-        if (g->world > 1 || collective) {
-            p.output_sum = 1;
-            GHIP_TRY(g, hipSetDevice(h->device));
-            GHIP_TRY(g, g->partial[(size_t)i].ensure(bytes));
-            dst = g->partial[(size_t)i].p;
-        } else p.output_sum = 0;   // one member, no collective: exactly cr_render_device
-        int32_t rc = cr_render_device(h, cam, &p, dst, nullptr);
-        if (rc != CR_OK) return gfail(g, rc, h->error);
+        int32_t rc = validate_render(h, cam, params);
+        if (rc != CR_OK) { note(rc, h->error); continue; }
+        if (cr_group_shard(params->samples, g->first + i, g->world, &ps[(size_t)i].sample_begin, &ps[(size_t)i].sample_count) != CR_OK) note(CR_ERR_INVALID_ARG, "samples must be >= 0");
+        ps[(size_t)i].output_sum = summed ? 1 : 0;   // one member, no collective: exactly cr_render_device
     }
-    // 2. one reduce of the sums to the root, then the divide there
-    if (g->world > 1 || collective) {
+    const size_t n = local_rc == CR_OK ? (size_t)cam->image_width * (size_t)cam->image_height * 3 : 0;
+    const bool f64 = params->real_type == CR_REAL_F64;
+    const size_t bytes = n * (f64 ? sizeof(double) : sizeof(float));
+    if (summed) for (int i = 0; i < local && local_rc == CR_OK; i++) {
+        CrHandle* h = g->members[(size_t)i];
+        if (hipSetDevice(h->device) != hipSuccess || g->partial[(size_t)i].ensure(bytes) != hipSuccess ||
+            (collective && g->status[(size_t)i].ensure(sizeof(int32_t)) != hipSuccess)) { (void)hipGetLastError(); note(CR_ERR_HIP, "cannot allocate a member's buffer of per-pixel sums"); }
+    }
+    // 1. every local member renders its shard, asynchronously on its own stream
+    const char* fail_member = getenv("CRUCIBLE_GROUP_FAIL_MEMBER");   // tests: this member's render reports a failure after it was launched
+    for (int i = 0; i < local && local_rc == CR_OK; i++) {
+        CrHandle* h = g->members[(size_t)i];
+        int32_t rc = cr_render_device(h, cam, &ps[(size_t)i], summed ? g->partial[(size_t)i].p : d_out, nullptr);
+        if (rc == CR_OK && fail_member && atoi(fail_member) == g->first + i) rc = fail(h, CR_ERR_HIP, "render failure injected by CRUCIBLE_GROUP_FAIL_MEMBER");
+        if (rc != CR_OK) note(rc, h->error);
+    }
+    // a collective call that fails leaves peers behind inside it: nothing more can be agreed on through these communicators
+    auto poison = [&](const std::string& what) {
+        g->poisoned = true;
+        RcclApi& api = rccl_api();
+        for (size_t i = 0; i < g->comms.size(); i++) if (g->comms[i]) { (void)hipSetDevice(g->members[i]->device); if (api.CommAbort) (void)api.CommAbort(g->comms[i]); g->comms[i] = nullptr; }
+        for (CrHandle* h : g->members) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); }
+        return gfail(g, CR_ERR_HIP, what);
+    };
+    // 2. do all members of the whole group stand?  (min over "1 = fine")
+    bool all_fine = local_rc == CR_OK;
+    if (collective) {
+        RcclApi& api = rccl_api();
+        const int32_t mine = local_rc == CR_OK ? 1 : 0;
+        bool ok = true;
+        for (int i = 0; i < local && ok; i++) {
+            CrHandle* h = g->members[(size_t)i];
+            ok = hipSetDevice(h->device) == hipSuccess && g->status[(size_t)i].ensure(sizeof(int32_t)) == hipSuccess &&
+                 hipMemcpyAsync(g->status[(size_t)i].p, &mine, sizeof mine, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+        }
+        if (!ok) return poison("cannot stage the group's status word");
+        ncclResult_t r = api.GroupStart();
+        for (int i = 0; i < local && r == ncclSuccess; i++) {
+            CrHandle* h = g->members[(size_t)i];
+            (void)hipSetDevice(h->device);
+            r = api.AllReduce(g->status[(size_t)i].p, g->status[(size_t)i].p, 1, ncclInt32, ncclMin, g->comms[(size_t)i], h->stream);
+        }
+        if (r == ncclSuccess) r = api.GroupEnd(); else (void)api.GroupEnd();
+        if (r != ncclSuccess) return poison(std::string("ncclAllReduce of the status word: ") + api.GetErrorString(r));
+        int32_t agreed = 1;
+        for (int i = 0; i < local; i++) {
+            CrHandle* h = g->members[(size_t)i];
+            int32_t v = 0;
+            if (hipSetDevice(h->device) != hipSuccess || hipMemcpyAsync(&v, g->status[(size_t)i].p, sizeof v, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                hipStreamSynchronize(h->stream) != hipSuccess) return poison("cannot read the group's status word");
+            agreed = std::min(agreed, v);
+        }
+        all_fine = agreed == 1;
+    }
+    if (!all_fine) {   // every rank is here: wait for what was launched and report
+        for (CrHandle* h : g->members) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); }
+        if (local_rc != CR_OK) return gfail(g, local_rc, local_err);
+        return gfail(g, CR_ERR_PEER, "another member of the group failed its render; nothing was reduced");
+    }
+    // 3. one reduce of the sums to the root, then the divide there
+    if (summed) {
         CrHandle* root = g->members[0];
         if (root_here) { GHIP_TRY(g, hipSetDevice(root->device)); GHIP_TRY(g, hipEventRecord(g->ev0, root->stream)); }
         if (g->same_device_sum) {   // every member is on the root's device: wait for their renders, then add in member order
@@ -1968,14 +2099,15 @@ int32_t cr_group_render(CrGroup* g, const CrCameraDesc* cam, const CrRenderParam
         if (collective) {
             RcclApi& api = rccl_api();
             const ncclDataType_t dt = f64 ? ncclDouble : ncclFloat;
-            NCCL_TRY(g, api, api.GroupStart());
-            for (int i = 0; i < local; i++) {
+            ncclResult_t r = api.GroupStart();
+            for (int i = 0; i < local && r == ncclSuccess; i++) {
                 CrHandle* h = g->members[(size_t)i];
-                GHIP_TRY(g, hipSetDevice(h->device));
+                (void)hipSetDevice(h->device);
                 void* buf = g->partial[(size_t)i].p;   // in place on the root
-                NCCL_TRY(g, api, api.Reduce(buf, buf, n, dt, ncclSum, 0, g->comms[(size_t)i], h->stream));
+                r = api.Reduce(buf, buf, n, dt, ncclSum, 0, g->comms[(size_t)i], h->stream);
             }
-            NCCL_TRY(g, api, api.GroupEnd());
+            if (r == ncclSuccess) r = api.GroupEnd(); else (void)api.GroupEnd();
+            if (r != ncclSuccess) return poison(std::string("ncclReduce: ") + api.GetErrorString(r));
         }
         if (root_here) {
             GHIP_TRY(g, hipSetDevice(root->device));
@@ -1986,22 +2118,23 @@ int32_t cr_group_render(CrGroup* g, const CrCameraDesc* cam, const CrRenderParam
             GHIP_TRY(g, hipEventRecord(g->ev1, root->stream));
         }
     }
-    // 3. wait for every local stream
+    // 4. wait for every local stream; a queue-pipeline wave that gave up leaves an incomplete image behind
     for (CrHandle* h : g->members) { GHIP_TRY(g, hipSetDevice(h->device)); GHIP_TRY(g, hipStreamSynchronize(h->stream)); }
+    for (CrHandle* h : g->members) { int32_t rc = check_queue_abort(h); if (rc != CR_OK) return gfail(g, rc, h->error); }
     if (stats) {
         memset(stats, 0, sizeof *stats);
         stats->members = g->world; stats->used_rccl = collective ? 1 : 0;
         const int64_t npix = (int64_t)cam->image_width * cam->image_height;
         for (int i = 0; i < local; i++) {
             CrStats s;
-            int32_t rc = member_stats(g->members[(size_t)i], npix * counts[(size_t)i], &s);
+            int32_t rc = member_stats(g->members[(size_t)i], npix * ps[(size_t)i].sample_count, &s);
             if (rc != CR_OK) return gfail(g, rc, g->members[(size_t)i]->error);
             stats->render.samples += s.samples; stats->render.segments += s.segments; stats->render.node_tests += s.node_tests;
             stats->render.prim_tests += s.prim_tests; stats->render.texel_fetches += s.texel_fetches;
             stats->render.kernel_ms = std::max(stats->render.kernel_ms, s.kernel_ms);
             stats->render.upload_ms = std::max(stats->render.upload_ms, s.upload_ms);
         }
-        if (root_here && (g->world > 1 || collective)) {
+        if (root_here && summed) {
             float ms = 0;
             GHIP_TRY(g, hipSetDevice(g->members[0]->device));
             GHIP_TRY(g, hipEventElapsedTime(&ms, g->ev0, g->ev1));
@@ -2011,23 +2144,30 @@ int32_t cr_group_render(CrGroup* g, const CrCameraDesc* cam, const CrRenderParam
     return CR_OK;
 }
 
+int32_t cr_group_render(CrGroup* g, const CrCameraDesc* cam, const CrRenderParams* params, void* d_out, CrGroupStats* stats) {
+    return group_render_impl(g, cam, params, d_out, stats, CR_OK, nullptr);
+}
+
 int32_t cr_group_render_host(CrGroup* g, const CrCameraDesc* cam, const CrRenderParams* params, void* h_out, CrGroupStats* stats) {
     if (!g) return CR_ERR_INVALID_ARG;
     if (!cam || !params) return gfail(g, CR_ERR_INVALID_ARG, "null camera or params");
+    DeviceGuard guard;
     const bool root_here = g->first == 0;
-    if (root_here && !h_out) return gfail(g, CR_ERR_INVALID_ARG, "the root member needs an output buffer");
-    if (cam->image_width < 1 || cam->image_height < 1) return gfail(g, CR_ERR_INVALID_ARG, "image size must be positive");
     CrHandle* root = g->members[0];
-    const size_t n = (size_t)cam->image_width * (size_t)cam->image_height * 3;
+    const bool sized = cam->image_width >= 1 && cam->image_height >= 1;
+    const size_t n = sized ? (size_t)cam->image_width * (size_t)cam->image_height * 3 : 0;
     const size_t bytes = n * real_size(params->real_type);
     void* d_out = nullptr;
-    if (root_here) {
-        GHIP_TRY(g, hipSetDevice(root->device));
-        GHIP_TRY(g, root->out_buf.ensure(bytes));
+    // what only the root can get wrong goes into the agreement step, so the other ranks are not left in the collective
+    int32_t pre_rc = CR_OK;
+    const char* pre_msg = nullptr;
+    if (root_here && !h_out) { pre_rc = CR_ERR_INVALID_ARG; pre_msg = "the root member needs an output buffer"; }
+    else if (root_here && sized) {
+        if (hipSetDevice(root->device) != hipSuccess || root->out_buf.ensure(bytes) != hipSuccess) { (void)hipGetLastError(); pre_rc = CR_ERR_HIP; pre_msg = "cannot allocate the root's output buffer"; }
         d_out = root->out_buf.p;
     }
     CrGroupStats local;
-    int32_t rc = cr_group_render(g, cam, params, d_out, stats ? stats : &local);
+    int32_t rc = group_render_impl(g, cam, params, d_out, stats ? stats : &local, pre_rc, pre_msg);
     if (rc != CR_OK || !root_here) return rc;
     GHIP_TRY(g, hipSetDevice(root->device));
     GHIP_TRY(g, hipMemcpyAsync(h_out, d_out, bytes, hipMemcpyDeviceToHost, root->stream));

@@ -21,6 +21,8 @@ struct RcclApi {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
@@ -46,6 +48,8 @@ RcclApi& rccl_api() {
         api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
         api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
         api.Reduce = (decltype(api.Reduce))sym("ncclReduce");
+        api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+        api.CommAbort = (decltype(api.CommAbort))sym("ncclCommAbort");
         api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
         api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
         api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
@@ -78,6 +82,8 @@ struct CrGroup {
     std::vector<ncclComm_t> comms;     // one per local member; empty: no collective (one-member group)
     bool same_device_sum = false;      // tests: members share a device and their sums are added by group_add_kernel
     std::vector<DevBuf> partial;       // per local member: W*H*3 raw sums of its shard
+    std::vector<DevBuf> status;        // per local member: the 4-byte "my render is fine" word of the agreement step
+    bool poisoned = false;             // a collective call failed: peers may still be inside it, the communicators are gone
     int first = 0;                     // group-wide index of members[0]
     int world = 1;                     // members in the whole group
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // on the root member's stream: reduce + divide
@@ -85,6 +91,13 @@ struct CrGroup {
 };
 
 namespace {
+
+// Restores the calling thread's current HIP device when a cr_group_* entry point returns (they visit every member's).
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) { dev = -1; (void)hipGetLastError(); } }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
 
 int32_t gfail(CrGroup* g, int32_t code, const std::string& msg) {
     if (g) g->error = msg; else g_group_create_error = msg;
@@ -112,6 +125,7 @@ void group_free(CrGroup* g) {
         if (!g->members[i]) continue;
         (void)hipSetDevice(g->members[i]->device);
         if (i < g->partial.size()) g->partial[i].release();
+        if (i < g->status.size()) g->status[i].release();
         if (i == 0) { if (g->ev0) (void)hipEventDestroy(g->ev0); if (g->ev1) (void)hipEventDestroy(g->ev1); }
         cr_destroy(g->members[i]);
     }

@@ -166,6 +166,14 @@ template <typename real> struct alignas(16) EntryO {
 };
 template <typename real, bool ORD> struct EntryOf { using type = Entry<real>; };
 template <typename real> struct EntryOf<real, true> { using type = EntryO<real>; };
+// f64 kernels: the f32 SCREENING copy of a wrapper -- the box rounded to f32, the same links.  The walk decides most box
+// tests on this 32-byte record (half the bytes of Entry<double>) and reads the f64 box only when the f32 result is too
+// close to call (screen_step below; DESIGN.md section 3.4 has the error bound).
+struct alignas(16) ScreenEntry {
+    float b[6];
+    int32_t skip;
+    int32_t leaf;
+};
 constexpr int32_t kLeafRun = 0x40000000;
 constexpr int32_t kLeafPseudo = 0x20000000;   // with kLeafRun: the record stands for a primitive / list that BVHWrapper::hit tests without a box
 constexpr int32_t kLeafRunIndex = 0x1fffffff;
@@ -221,6 +229,7 @@ template <typename real> struct KernelArgs {
     const Key<real>* keys;
     const Key<real>* cam_keys;   // this launch's camera keyframes (look_from keys, then look_at keys)
     const int32_t* leaf_runs;    // (first, count) pairs for the leaves flagged kLeafRun
+    const ScreenEntry* screen;   // f64, unordered trees: one screening record per wrapper (null: every test in f64)
     int32_t n_entries, n_prims, n_mats, n_texs;
     int32_t lds_entries;      // entries staged in LDS (all of them, or the top levels of a large tree)
     int32_t lds_side;         // RES_TOP: materials and textures follow the entry window in LDS (they are small even when
@@ -336,7 +345,7 @@ template <typename real> CR_HD CamFrame<real> camera_frame(const CamConst<real>&
 #ifdef CR_DIAG
 enum { DG_BOX_WAVE = 0, DG_BOX_LANE, DG_PRIM_WAVE, DG_PRIM_LANE, DG_ROUND_WAVE, DG_ROUND_LANE, DG_LEAFPH_WAVE, DG_LEAFPH_LANE,
        DG_SHADE_WAVE, DG_SHADE_LANE, DG_LAMB_LANE, DG_METAL_LANE, DG_DIEL_LANE, DG_SKY_LANE, DG_RUV_WAVE, DG_RUV_LANE,
-       DG_REGEN_WAVE, DG_REGEN_LANE, DG_OUTER_WAVE, DG_UNWIND_WAVE, DG_UNWIND_LANE, DG_HITSH_WAVE, DG_HITSH_LANE, DG_N };
+       DG_REGEN_WAVE, DG_REGEN_LANE, DG_OUTER_WAVE, DG_UNWIND_WAVE, DG_UNWIND_LANE, DG_HITSH_WAVE, DG_HITSH_LANE, DG_BAND_WAVE, DG_BAND_LANE, DG_N };
 struct Diag { uint32_t v[DG_N]; };
 #define CR_DIAG_LEADER() ((threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)__ballot(1)) - 1))
 #define CR_DIAG_HIT(dg, wave_i, lane_i) do { if (dg) { (dg)->v[lane_i]++; if (CR_DIAG_LEADER()) (dg)->v[wave_i]++; } } while (0)
@@ -922,6 +931,25 @@ CR_D Entry<real> fetch_entry_ordered(const Entry<real>* lds, const Entry<real>* 
     return rd((const EntryO<real>*)glob);
 }
 
+// A screening record, from the LDS copy or from global memory (RES_TOP: the LDS window holds the first lds_n of them).
+template <int RES>
+CR_D ScreenEntry fetch_screen(const ScreenEntry* lds, const ScreenEntry* glob, int32_t lds_n, int32_t idx) {
+    if (RES == RES_LDS) return lds[idx];
+    if (RES == RES_TOP) {
+        ScreenEntry e;
+        uint32_t* o = reinterpret_cast<uint32_t*>(&e);
+        if (idx < lds_n) {
+            LdsPtr<uint32_t> s = (LdsPtr<uint32_t>)(const void*)(lds + idx);
+            for (int k = 0; k < 8; k++) o[k] = s[k];
+        } else {
+            GlobPtr<uint32_t> s = (GlobPtr<uint32_t>)(const void*)(glob + idx);
+            for (int k = 0; k < 8; k++) o[k] = s[k];
+        }
+        return e;
+    }
+    return glob[idx];
+}
+
 // The per-ray state of BVHWrapper::hit's walk, kept in registers so a walk can be suspended and resumed.
 template <typename real> struct WalkState {
     V3<real> inv;        // 1 / direction
@@ -949,23 +977,95 @@ template <typename real> CR_D void walk_begin(WalkState<real>& w, V3<real> rd) {
 // Per lane this is exactly BVHWrapper::hit's sequence (bvhwrapper.rs:96-126); the round structure only decides
 // when lanes wait for each other.
 // ORD: the ordered layout (EntryO behind the same pointers) -- near child first, per-octant skip links.
-template <typename real, int RES, bool ANIM, bool ORD = false>
+// f64, unordered trees, A.screen set: Aabb::hit decided on the f32 screening record wherever f32 can decide it.
+// Notation: b, o, inv = an f64 box plane, the origin component and 1/direction on that axis; bf, of, if their f32
+// roundings; u = 2^-24; T = (b - o) * inv; t32 = fl(fl(bf - of) * if) the f32 slab distance.  Then
+//     |t32 - T| <= 1.01 u |inv| (|b| + |o|) + 3.01 u |t32|          (three roundings of inputs, two of operations)
+// and, because |inv| |b| <= |T| + |inv| |o|,
+//     |t32 - T| <= 4.03 u |t32| + 2.03 u |inv| |o|                   (the f64 test's own roundings, 2^-52 |T|, vanish in the slack).
+// lo32 = max(nears, 0.001) and hi32 = min(fars, tmax32): an operand can decide the f64 result only if its own value lies
+// within the two errors of the f32 winner, so the end's error is bounded by the same expression in |lo32| resp. |hi32|
+// (to first order in u); an interval end that wins was rounded once (u |end|); the subtraction rounds once more.  With
+// M = max(|lo32|, |hi32|) and Q = max over the axes of |if of|,
+//     TH = 2^-20 M + 2^-21 Q + 2^-147 max |if| + 1e-35
+// is at least 1.5 times the largest possible |(hi32 - lo32) - (hi - lo)| (10.1 u M + 4.06 u Q; the last two terms cover
+// a box plane or origin component below the normal f32 range and a product that underflows).  Hence hi32 - lo32 < -TH proves Aabb::hit's
+// `max <= min` (a miss), hi32 - lo32 > TH proves a hit, and only a lane with |hi32 - lo32| <= TH evaluates Aabb::hit in f64
+// on the f64 box.  Overflow and NaN land there too (every comparison with them is false), and the round uses the screen only
+// when |if| lies in [2^-100, 2^100] and |of| <= 2^100 on every axis.  The decisions -- hence the walk, the counters and the image -- are those of the f64 test.
+// SCREEN is a kernel variant of its own (f64, unordered trees read from global memory): a kernel that carried both the
+// f32 loop and the f64 min/max loop lost 5 % on the teapot frames to register pressure.  In a SCREEN kernel a ray whose
+// 1/direction is infinite, or outside the f32 range above, walks with Aabb::hit's compare/select form (valid for every ray).
+template <typename real, int RES, bool ANIM, bool ORD = false, bool SCREEN = false>
 CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, const Prim<real>* prims, V3<real> ro, V3<real> rd, real rtime,
-                     WalkState<real>& w, bool walking, uint32_t budget, unsigned long long& c_node, uint32_t& c_prim, Diag* dg = nullptr) {
+                     WalkState<real>& w, bool walking, uint32_t budget, unsigned long long& c_node, uint32_t& c_prim, Diag* dg = nullptr,
+                     const ScreenEntry* lds_screen = nullptr) {
+    static_assert(!SCREEN || (std::is_same<real, double>::value && !ORD), "screening records: f64, unordered trees");
     const real tmin = real(0.001);
     const int32_t n_entries = A.n_entries;
+    // RES_TOP with screening: the LDS window holds screening records, every f64 record is read from global memory
+    const int32_t lds_n64 = (SCREEN && RES == RES_TOP) ? 0 : A.lds_entries;
     int32_t leaf = -1;
     if (walking) {
         CR_DIAG_HIT(dg, DG_ROUND_WAVE, DG_ROUND_LANE);
-        if (!w.exact_box) {
+        // SCREEN kernels: steps the f32 loop could not take -- one, for a lane it left at a box too close to call, or all of
+        // them for a ray outside its range -- are made below with Aabb::hit's own compare/select form on the f64 records
+        uint32_t exact_steps = w.exact_box ? 0xffffffffu : 0u;
+        if constexpr (SCREEN) {
+            const float ofx = (float)ro.x, ofy = (float)ro.y, ofz = (float)ro.z;
+            const float ifx = (float)w.inv.x, ify = (float)w.inv.y, ifz = (float)w.inv.z;
+            const float mo = r_max(r_max(__builtin_fabsf(ofx), __builtin_fabsf(ofy)), __builtin_fabsf(ofz));
+            const float pmax = r_max(r_max(__builtin_fabsf(ifx), __builtin_fabsf(ify)), __builtin_fabsf(ifz));
+            const float pmin = r_min(r_min(__builtin_fabsf(ifx), __builtin_fabsf(ify)), __builtin_fabsf(ifz));
+            const bool screened = !w.exact_box && pmin >= 0x1.0p-100f && pmax <= 0x1.0p100f && mo <= 0x1.0p100f;
+            if (!screened) exact_steps = 0xffffffffu;
+            else {
+                const float qx = __builtin_fabsf(ofx * ifx), qy = __builtin_fabsf(ofy * ify), qz = __builtin_fabsf(ofz * ifz);
+                const Pair<float> fox = {ofx, ofx}, foy = {ofy, ofy}, foz = {ofz, ofz};
+                const Pair<float> fix = {ifx, ifx}, fiy = {ify, ify}, fiz = {ifz, ifz};
+                const float tminf = 0.001f;
+                float tmaxf = (float)w.best_t;   // tmax cannot change inside the loop
+                // the part of TH that does not depend on the box: 2^-21 Q, plus what rounding a box plane or an origin component
+                // BELOW the normal f32 range can add (2^-149 each, times |if| <= 2^100), plus a product that underflows
+                const float th0 = __builtin_fmaf(0x1.0p-21f, r_max(r_max(qx, qy), qz), __builtin_fmaf(pmax * 0x1.0p-100f, 0x1.0p-47f, 1e-35f));
+                asm volatile("" : "+v"(tmaxf));   // keep it in a register: the allocator would re-convert tmax at every step
+                uint32_t nodes = 0;
+                // `it` is the same in every lane still in the loop (a scalar register)
+                for (uint32_t it = 0; w.idx < n_entries; it++) {
+                    const ScreenEntry se = fetch_screen<RES>(lds_screen, A.screen, A.lds_entries, w.idx);
+                    const Pair<float> tx = (Pair<float>{se.b[0], se.b[1]} - fox) * fix;
+                    const Pair<float> ty = (Pair<float>{se.b[2], se.b[3]} - foy) * fiy;
+                    const Pair<float> tz = (Pair<float>{se.b[4], se.b[5]} - foz) * fiz;
+                    const float nx = r_min(tx.x, tx.y), ny = r_min(ty.x, ty.y), nz = r_min(tz.x, tz.y);
+                    const float fx = r_max(tx.x, tx.y), fy = r_max(ty.x, ty.y), fz = r_max(tz.x, tz.y);
+                    const float lo = r_max(r_max(nx, ny), r_max(nz, tminf));
+                    const float hi = r_min(r_min(fx, fy), r_min(fz, tmaxf));
+                    const float th = __builtin_fmaf(0x1.0p-20f, r_max(__builtin_fabsf(lo), __builtin_fabsf(hi)), th0);
+                    const float d = hi - lo;
+                    nodes++;
+                    CR_DIAG_HIT(dg, DG_BOX_WAVE, DG_BOX_LANE);
+                    bool miss = d < 0.0f;
+                    if (__builtin_expect(!(__builtin_fabsf(d) > th), 0)) {   // too close to call in f32: Aabb::hit in f64 on the f64 box
+                        CR_DIAG_HIT(dg, DG_BAND_WAVE, DG_BAND_LANE);
+                        const Entry<real> e = fetch_entry<real, RES>(lds_entries, A.entries, lds_n64, w.idx);
+                        miss = !box_hit(e.b, ro, w.inv, tmin, w.best_t);
+                    }
+                    const bool inner = se.leaf < 0;
+                    w.idx = (inner && !miss) ? -se.leaf : se.skip;
+                    if (!(miss || inner)) { leaf = se.leaf; break; }
+                    if (it + 1 == budget) break;
+                }
+                c_node += nodes;
+            }
+        } else if (!w.exact_box) {
             const Pair<real> ox = {ro.x, ro.x}, oy = {ro.y, ro.y}, oz = {ro.z, ro.z};
             const Pair<real> ix = {w.inv.x, w.inv.x}, iy = {w.inv.y, w.inv.y}, iz = {w.inv.z, w.inv.z};
             // `it` is the same in every lane still in the loop (a scalar register); tmax cannot change inside it
             const real tmax = w.best_t;
             uint32_t nodes = 0;
             for (uint32_t it = 0; w.idx < n_entries; it++) {
-                const Entry<real> e = ORD ? fetch_entry_ordered<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx, w.oct)
-                                          : fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx);
+                const Entry<real> e = ORD ? fetch_entry_ordered<real, RES>(lds_entries, A.entries, lds_n64, w.idx, w.oct)
+                                          : fetch_entry<real, RES>(lds_entries, A.entries, lds_n64, w.idx);
                 nodes++;
                 CR_DIAG_HIT(dg, DG_BOX_WAVE, DG_BOX_LANE);
                 const bool miss = box_miss_fast(e.b, ox, oy, oz, ix, iy, iz, tmin, tmax);
@@ -975,15 +1075,14 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
                 if (it + 1 == budget) break;
             }
             c_node += nodes;
-        } else {
-            while (w.idx < n_entries) {
-                const Entry<real> e = ORD ? fetch_entry_ordered<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx, w.oct)
-                                          : fetch_entry<real, RES>(lds_entries, A.entries, A.lds_entries, w.idx);
-                c_node++;
-                bool hit = box_hit(e.b, ro, w.inv, tmin, w.best_t);
-                w.idx = (hit && e.leaf < 0) ? (ORD ? ordered_near(e.leaf, w.oct) : -e.leaf) : e.skip;
-                if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
-            }
+        }
+        for (; exact_steps != 0u && w.idx < n_entries; exact_steps--) {
+            const Entry<real> e = ORD ? fetch_entry_ordered<real, RES>(lds_entries, A.entries, lds_n64, w.idx, w.oct)
+                                      : fetch_entry<real, RES>(lds_entries, A.entries, lds_n64, w.idx);
+            c_node++;
+            bool hit = box_hit(e.b, ro, w.inv, tmin, w.best_t);
+            w.idx = (hit && e.leaf < 0) ? (ORD ? ordered_near(e.leaf, w.oct) : -e.leaf) : e.skip;
+            if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
         }
     }
     if (leaf >= 0) {
@@ -1047,11 +1146,12 @@ template <typename real> struct MaxBlock { static constexpr int value = 1024; };
 // -- about 48 global atomics per 1024 samples instead of 3 per sample (global atomics execute at the memory side, one
 // request per lane when the lanes' addresses are scattered).  A straggler whose tile has already been flushed adds to
 // the global sums directly.
-template <typename real, int RES, bool ANIM, bool ORD, bool CAMK = false, bool RELAX = false>
+template <typename real, int RES, bool ANIM, bool ORD, bool CAMK = false, bool RELAX = false, bool SCREEN = false>
 CR_D void pathtrace_body(const KernelArgs<real>& A) {
     using EntryT = typename EntryOf<real, ORD>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Entry<real>* lds_entries = nullptr;
+    const ScreenEntry* lds_screen = nullptr;
     const Prim<real>* prims = A.prims;
     const Mat<real>* mats = A.mats;
     const Tex<real>* texs = A.texs;
@@ -1061,8 +1161,12 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
             uint32_t* d = (uint32_t*)(smem + off);
             for (size_t i = threadIdx.x; i < bytes / 4; i += blockDim.x) d[i] = s[i];
         };
-        copy(A.entries, 0, (size_t)A.lds_entries * sizeof(EntryT));
+        // RES_TOP with screening records: the window holds those (twice as many wrappers in the same bytes)
+        constexpr bool screen_window = SCREEN && RES == RES_TOP;
+        const size_t window_rec = screen_window ? sizeof(ScreenEntry) : sizeof(EntryT);
+        copy(screen_window ? (const void*)A.screen : (const void*)A.entries, 0, (size_t)A.lds_entries * window_rec);
         lds_entries = (const Entry<real>*)smem;
+        if (screen_window) lds_screen = (const ScreenEntry*)smem;
         if (RES == RES_LDS) {   // the whole scene: entries | prims | mats | texs, each 16-B aligned
             size_t o1 = (((size_t)A.n_entries * sizeof(EntryT) + 15) & ~(size_t)15);
             size_t o2 = o1 + (((size_t)A.n_prims * sizeof(Prim<real>) + 15) & ~(size_t)15);
@@ -1073,8 +1177,13 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
             prims = (const Prim<real>*)(smem + o1);
             mats = (const Mat<real>*)(smem + o2);
             texs = (const Tex<real>*)(smem + o3);
+            if constexpr (SCREEN) {   // ... | screening records
+                size_t o4 = o3 + (((size_t)A.n_texs * sizeof(Tex<real>) + 15) & ~(size_t)15);
+                copy(A.screen, o4, (size_t)A.n_entries * sizeof(ScreenEntry));
+                lds_screen = (const ScreenEntry*)(smem + o4);
+            }
         } else if (A.lds_side) {   // RES_TOP: entry window | mats | texs
-            size_t o2 = (((size_t)A.lds_entries * sizeof(EntryT) + 15) & ~(size_t)15);
+            size_t o2 = (((size_t)A.lds_entries * window_rec + 15) & ~(size_t)15);
             size_t o3 = o2 + (((size_t)A.n_mats * sizeof(Mat<real>) + 15) & ~(size_t)15);
             copy(A.mats, o2, (size_t)A.n_mats * sizeof(Mat<real>));
             copy(A.texs, o3, (size_t)A.n_texs * sizeof(Tex<real>));
@@ -1243,7 +1352,7 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
         // shading changes.
         if (__ballot(state == ST_WALK)) {
             for (;;) {
-                walk_round<real, RES, ANIM, ORD>(A, lds_entries, prims, ro, rd, rtime, ws, state == ST_WALK, A.walk_round_steps, c_node, c_prim, dgp);
+                walk_round<real, RES, ANIM, ORD, SCREEN>(A, lds_entries, prims, ro, rd, rtime, ws, state == ST_WALK, A.walk_round_steps, c_node, c_prim, dgp, lds_screen);
                 if (state == ST_WALK && ws.idx >= n_entries) state = ST_SHADE;
                 const uint64_t walking = __ballot(state == ST_WALK);
                 if (!walking || 64u - (uint32_t)__popcll(walking) >= A.walk_exit_lanes) break;
@@ -1344,9 +1453,9 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
 
     }
 }
-template <typename real, int RES, bool ANIM, bool ORD = false, bool CAMK = false, bool RELAX = false>
+template <typename real, int RES, bool ANIM, bool ORD = false, bool CAMK = false, bool RELAX = false, bool SCREEN = false>
 __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const KernelArgs<real> A) {
-    pathtrace_body<real, RES, ANIM, ORD, CAMK, RELAX>(A);
+    pathtrace_body<real, RES, ANIM, ORD, CAMK, RELAX, SCREEN>(A);
 }
 
 // The same kernel compiled for 6 waves per SIMD (<= 80 VGPRs, 512-thread groups), for trees far larger than the
@@ -1358,6 +1467,18 @@ template <typename real, bool ANIM, bool ORD = false, bool CAMK = false, bool RE
 __global__ void __attribute__((amdgpu_flat_work_group_size(64, LatencyBlock), amdgpu_waves_per_eu(6, 6)))
 pathtrace_kernel_latency(const KernelArgs<real> A) {
     pathtrace_body<real, RES_TOP, ANIM, ORD, CAMK, RELAX>(A);
+}
+
+// The screening records of a wrapper array: boxes rounded to the nearest f32 (the band of walk_round allows for either
+// direction), links copied.  Run after every upload and after every refit of the f64 boxes.
+__global__ void __launch_bounds__(256) screen_from_entries_kernel(const Entry<double>* e, ScreenEntry* s, int32_t n) {
+    const int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const Entry<double> v = e[i];
+    ScreenEntry o;
+    for (int k = 0; k < 6; k++) o.b[k] = (float)v.b[k];
+    o.skip = v.skip; o.leaf = v.leaf;
+    s[i] = o;
 }
 
 // CR_SUM_RELAXED: the fixed-point sums become the frame -- sum * 2^-S, divided by the sample count unless the raw

@@ -17,6 +17,7 @@
 #include "../../include/crucible_hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -561,17 +562,34 @@ public:
     size_t compute_frame_count() const { return (size_t)std::ceil(duration * (double)frame_rate); }   // scene/mod.rs:324-330
 
     // ---- Camera::render over the library (scene/mod.rs:283-347)
-    // The render proper: W*H*3 reals of `real_type` into `buf` (sized for either scalar type).
-    int32_t render_frame(CrHandle* h, std::vector<double>& buf, CrStats* stats = nullptr) const {
+    // Wall-clock phases of the last render_scene call (a measurement aid: the reference's one benchmark times the whole
+    // of render_scene -- BVH build, render, file -- benches/renderer_benchmark.rs:16-42).
+    struct Timing { double create_ms = 0, flatten_ms = 0, upload_ms = 0, bvh_build_ms = 0, render_ms = 0, write_ms = 0, total_ms = 0, kernel_ms = 0; size_t frames = 0; };
+    Timing timing;
+    int sum_order = CR_SUM_DEFAULT;    // CrRenderParams.sum_order
+    static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+    CrCameraDesc camera_desc(std::vector<CrKeyframe>& fk, std::vector<CrKeyframe>& ak) const {
         const Camera& c = scene_cam;
-        std::vector<CrKeyframe> fk = c.look_from_tl.keyframes(), ak = c.look_at_tl.keyframes();
-        CrCameraDesc cd{c.image_width, c.image_height, c.vfov_degrees, c.defocus_angle_degrees, c.focus_dist,
-                        {c.look_from_tl.start_pos.x, c.look_from_tl.start_pos.y, c.look_from_tl.start_pos.z},
-                        {c.look_at_tl.start_pos.x, c.look_at_tl.start_pos.y, c.look_at_tl.start_pos.z},
-                        {c.vup.x, c.vup.y, c.vup.z}, (int32_t)fk.size(), (int32_t)ak.size(), fk.data(), ak.data()};
-        CrRenderParams p{(int32_t)c.samples, 0, (int32_t)c.samples, (int32_t)c.max_depth, seed, (int32_t)c.frame, real_type,
-                         c.frame_rate, c.shutter_angle, 0, refit_boxes ? 1 : 0};
-        buf.resize((size_t)c.image_width * c.image_height * 3);
+        fk = c.look_from_tl.keyframes(); ak = c.look_at_tl.keyframes();
+        return CrCameraDesc{c.image_width, c.image_height, c.vfov_degrees, c.defocus_angle_degrees, c.focus_dist,
+                            {c.look_from_tl.start_pos.x, c.look_from_tl.start_pos.y, c.look_from_tl.start_pos.z},
+                            {c.look_at_tl.start_pos.x, c.look_at_tl.start_pos.y, c.look_at_tl.start_pos.z},
+                            {c.vup.x, c.vup.y, c.vup.z}, (int32_t)fk.size(), (int32_t)ak.size(), fk.data(), ak.data()};
+    }
+    CrRenderParams render_params(size_t frame) const {
+        const Camera& c = scene_cam;
+        CrRenderParams p{(int32_t)c.samples, 0, (int32_t)c.samples, (int32_t)c.max_depth, seed, (int32_t)frame, real_type,
+                         c.frame_rate, c.shutter_angle, 0, refit_boxes ? 1 : 0, sum_order, 0};
+        return p;
+    }
+    // The render proper: W*H*3 reals of `real_type` into `buf` (sized for either scalar type), at the camera's frame
+    // counter or at `frame`.
+    int32_t render_frame(CrHandle* h, std::vector<double>& buf, CrStats* stats = nullptr, int64_t frame = -1) const {
+        std::vector<CrKeyframe> fk, ak;
+        CrCameraDesc cd = camera_desc(fk, ak);
+        CrRenderParams p = render_params(frame < 0 ? (size_t)scene_cam.frame : (size_t)frame);
+        buf.resize((size_t)scene_cam.image_width * scene_cam.image_height * 3);
         return cr_render_host(h, &cd, &p, buf.data(), stats);
     }
     // The file: "ppm" = the reference's ASCII P3 (camera/mod.rs:286,306-311); "p6" / "png" = SURVEY 8(f) row 3,
@@ -582,114 +600,146 @@ public:
         int32_t rc = frame_format == "png" ? cr_write_png(path.c_str(), buf.data(), real_type, c.image_width, c.image_height)
                    : frame_format == "p6" ? cr_write_ppm_binary(path.c_str(), buf.data(), real_type, c.image_width, c.image_height)
                                           : cr_write_ppm(path.c_str(), buf.data(), real_type, c.image_width, c.image_height);
-        if (rc == CR_OK) fprintf(stderr, "Successful render! Image stored at: %s\n", path.c_str());
+        if (rc == CR_OK && !quiet) fprintf(stderr, "Successful render! Image stored at: %s\n", path.c_str());
         return rc;
     }
-    int32_t render_image(CrHandle* h, const std::string& fname, CrStats* stats = nullptr) const {
+    bool quiet = false;   // no "Successful render!" line per frame
+    int32_t render_image(CrHandle* h, const std::string& fname, CrStats* stats = nullptr) {
         std::vector<double> buf;
+        double t0 = now_ms();
         int32_t rc = render_frame(h, buf, stats);
-        return rc == CR_OK ? write_frame(fname, buf) : rc;
+        double t1 = now_ms();
+        timing.render_ms += t1 - t0;
+        if (rc == CR_OK) { rc = write_frame(fname, buf); timing.write_ms += now_ms() - t1; timing.frames++; }
+        return rc;
     }
     // Camera::render across several devices: cr_group_render_host splits the sample indices, adds the per-pixel sums with
     // one RCCL reduce inside the library and hands back the mean.
     int32_t render_frame_group(CrGroup* g, std::vector<double>& buf, CrStats* stats = nullptr) const {
-        const Camera& c = scene_cam;
-        std::vector<CrKeyframe> fk = c.look_from_tl.keyframes(), ak = c.look_at_tl.keyframes();
-        CrCameraDesc cd{c.image_width, c.image_height, c.vfov_degrees, c.defocus_angle_degrees, c.focus_dist,
-                        {c.look_from_tl.start_pos.x, c.look_from_tl.start_pos.y, c.look_from_tl.start_pos.z},
-                        {c.look_at_tl.start_pos.x, c.look_at_tl.start_pos.y, c.look_at_tl.start_pos.z},
-                        {c.vup.x, c.vup.y, c.vup.z}, (int32_t)fk.size(), (int32_t)ak.size(), fk.data(), ak.data()};
-        CrRenderParams p{(int32_t)c.samples, 0, (int32_t)c.samples, (int32_t)c.max_depth, seed, (int32_t)c.frame, real_type,
-                         c.frame_rate, c.shutter_angle, 0, refit_boxes ? 1 : 0};
-        buf.resize((size_t)c.image_width * c.image_height * 3);
+        std::vector<CrKeyframe> fk, ak;
+        CrCameraDesc cd = camera_desc(fk, ak);
+        CrRenderParams p = render_params((size_t)scene_cam.frame);
+        buf.resize((size_t)scene_cam.image_width * scene_cam.image_height * 3);
         CrGroupStats gs;
         int32_t rc = cr_group_render_host(g, &cd, &p, buf.data(), &gs);
         if (stats) *stats = gs.render;
         return rc;
     }
-    // One frame of a movie on one member of the group (its own handle, its own host thread).
-    int32_t render_movie_frame(CrHandle* h, size_t frame, const std::string& stem, std::vector<double>& buf) const {
-        Scene copy = *this;                       // the camera's frame counter is per render
-        copy.scene_cam.frame = (uint32_t)frame;
-        int32_t rc = copy.render_frame(h, buf, nullptr);
-        return rc == CR_OK ? copy.write_frame(stem, buf) : rc;
-    }
-    int32_t render_scene_group(const std::string& fname, CrStats* stats) {
-        std::vector<int32_t> ids;
-        for (int i = 0; i < std::max(1, gpus); i++) ids.push_back(device + i);
-        CrGroup* g = nullptr;
-        int32_t rc = cr_group_create(ids.data(), (int32_t)ids.size(), &g);
-        if (rc != CR_OK) { fprintf(stderr, "Render failed. %s\n", cr_group_last_error(nullptr)); return rc; }
-        FlatScene f = flatten();
-        rc = cr_group_upload_scene(g, &f.desc);
-        if (rc == CR_OK && !is_movie) {
-            std::vector<double> buf;
-            rc = render_frame_group(g, buf, stats);
-            if (rc == CR_OK) rc = write_frame(fname, buf);
-        } else if (rc == CR_OK) {   // frames sharded round-robin, one host thread per device, no collective
-            if (mkdir(fname.c_str(), 0777) != 0 || mkdir((fname + "/artifacts").c_str(), 0777) != 0) rc = CR_ERR_IO;
-            const size_t frames = compute_frame_count(), digits = std::to_string(frames).size(), n = ids.size();
-            std::vector<int32_t> member_rc(n, CR_OK);
-            std::vector<std::thread> workers;
-            for (size_t m = 0; rc == CR_OK && m < n; m++)
-                workers.emplace_back([this, g, m, n, frames, digits, &fname, &member_rc] {
-                    std::vector<double> buf;
-                    for (size_t fr = m; fr < frames && member_rc[m] == CR_OK; fr += n) {
-                        std::string num = std::to_string(fr);
-                        num = std::string(digits - num.size(), '0') + num;
-                        member_rc[m] = render_movie_frame(cr_group_handle(g, (int32_t)m), fr, fname + "/artifacts/image" + num, buf);
-                    }
-                });
-            for (std::thread& t : workers) t.join();
-            for (int32_t r : member_rc) if (rc == CR_OK) rc = r;
-            if (rc == CR_OK) {
-                std::string cmd;
-                for (const std::string& a : mp4_command(fname, digits)) cmd += (cmd.empty() ? "" : " ") + (a.find_first_of("*()") != std::string::npos ? "'" + a + "'" : a);
-                fprintf(stderr, "Frames written. To assemble the movie: %s\n", cmd.c_str());
-            }
+    // render_movie (scene/mod.rs:295-322) for the frames first, first + step, ... on one handle: frame k is encoded and
+    // written by a helper thread while frame k+1 renders (two buffers; SURVEY 8(f) row 3 -- the reference formats and
+    // writes each frame before starting the next).  render_ms: time this thread spent inside renders; write_ms: time the
+    // helper threads spent encoding and writing (overlapped, so it is not part of the wall clock unless it is the longer one).
+    int32_t render_movie_frames(CrHandle* h, const std::string& fname, size_t first, size_t step, size_t frames, size_t digits,
+                                CrStats* stats, Timing* tm) const {
+        std::vector<double> bufs[2];
+        std::thread writers[2];
+        int32_t write_rc[2] = {CR_OK, CR_OK};
+        double write_ms[2] = {0, 0};
+        int32_t rc = CR_OK;
+        size_t k = 0;
+        for (size_t fr = first; rc == CR_OK && fr < frames; fr += step, k++) {
+            const int slot = (int)(k & 1);
+            if (writers[slot].joinable()) { writers[slot].join(); if (write_rc[slot] != CR_OK) { rc = write_rc[slot]; break; } }
+            std::string num = std::to_string(fr);
+            num = std::string(digits - num.size(), '0') + num;
+            CrStats st;
+            const double t0 = now_ms();
+            rc = render_frame(h, bufs[slot], &st, (int64_t)fr);
+            if (tm) { tm->render_ms += now_ms() - t0; tm->kernel_ms += st.kernel_ms; tm->frames++; }
+            if (stats) *stats = st;
+            if (rc != CR_OK) break;
+            const std::string stem = fname + "/artifacts/image" + num;
+            writers[slot] = std::thread([this, stem, slot, &bufs, &write_rc, &write_ms] {
+                const double w0 = now_ms();
+                write_rc[slot] = write_frame(stem, bufs[slot]);
+                write_ms[slot] += now_ms() - w0;
+            });
         }
-        if (rc != CR_OK) fprintf(stderr, "Render failed. %s\n", cr_group_last_error(g));
-        cr_group_destroy(g);
+        for (int s2 = 0; s2 < 2; s2++) if (writers[s2].joinable()) { writers[s2].join(); if (rc == CR_OK) rc = write_rc[s2]; }
+        if (tm) tm->write_ms += write_ms[0] + write_ms[1];
+        return rc;
+    }
+    void print_mp4_command(const std::string& fname, size_t digits) const {   // scene/mod.rs:319 would run this
+        std::string cmd;
+        for (const std::string& a : mp4_command(fname, digits)) cmd += (cmd.empty() ? "" : " ") + (a.find_first_of("*()") != std::string::npos ? "'" + a + "'" : a);
+        fprintf(stderr, "Frames written. To assemble the movie: %s\n", cmd.c_str());
+    }
+    // Several devices.  A still image splits its samples through cr_group_* (one collective).  A movie needs no collective:
+    // frames are independent (scene/mod.rs:307-316), so device m gets its own plain handle and its own host thread for the
+    // frames m, m + n, ... -- no communicator, no RCCL.
+    int32_t render_scene_group(const std::string& fname, CrStats* stats) {
+        const int n = std::max(1, gpus);
+        FlatScene f = flatten();
+        if (!is_movie) {
+            std::vector<int32_t> ids;
+            for (int i = 0; i < n; i++) ids.push_back(device + i);
+            CrGroup* g = nullptr;
+            int32_t rc = cr_group_create(ids.data(), (int32_t)ids.size(), &g);
+            if (rc != CR_OK) { fprintf(stderr, "Render failed. %s\n", cr_group_last_error(nullptr)); return rc; }
+            rc = cr_group_upload_scene(g, &f.desc);
+            std::vector<double> buf;
+            if (rc == CR_OK) rc = render_frame_group(g, buf, stats);
+            if (rc == CR_OK) rc = write_frame(fname, buf);
+            if (rc != CR_OK) fprintf(stderr, "Render failed. %s\n", cr_group_last_error(g));
+            cr_group_destroy(g);
+            return rc;
+        }
+        if (mkdir(fname.c_str(), 0777) != 0 || mkdir((fname + "/artifacts").c_str(), 0777) != 0) { fprintf(stderr, "Render failed. cannot create %s\n", fname.c_str()); return CR_ERR_IO; }
+        const size_t frames = compute_frame_count(), digits = std::to_string(frames).size();
+        std::vector<int32_t> member_rc((size_t)n, CR_OK);
+        std::vector<std::string> member_err((size_t)n);
+        std::vector<Timing> member_tm((size_t)n);
+        std::vector<std::thread> workers;
+        for (int m = 0; m < n; m++)
+            workers.emplace_back([this, m, n, frames, digits, &fname, &f, &member_rc, &member_err, &member_tm] {
+                CrHandle* h = nullptr;
+                int32_t rc = cr_create(device + m, &h);
+                if (rc != CR_OK) { member_rc[(size_t)m] = rc; member_err[(size_t)m] = cr_last_error(nullptr); return; }
+                rc = cr_upload_scene(h, &f.desc);
+                if (rc == CR_OK) rc = render_movie_frames(h, fname, (size_t)m, (size_t)n, frames, digits, nullptr, &member_tm[(size_t)m]);
+                if (rc != CR_OK) { member_rc[(size_t)m] = rc; member_err[(size_t)m] = cr_last_error(h); }   // the failing member's own message
+                cr_destroy(h);
+            });
+        for (std::thread& t : workers) t.join();
+        int32_t rc = CR_OK;
+        for (int m = 0; m < n; m++) {
+            timing.render_ms = std::max(timing.render_ms, member_tm[(size_t)m].render_ms); timing.write_ms = std::max(timing.write_ms, member_tm[(size_t)m].write_ms);
+            timing.kernel_ms += member_tm[(size_t)m].kernel_ms; timing.frames += member_tm[(size_t)m].frames;
+            if (member_rc[(size_t)m] != CR_OK) { fprintf(stderr, "Render failed on device %d. %s\n", device + m, member_err[(size_t)m].c_str()); if (rc == CR_OK) rc = member_rc[(size_t)m]; }
+        }
+        if (rc == CR_OK) print_mp4_command(fname, digits);
         return rc;
     }
     int32_t render_scene(const std::string& fname, CrStats* stats = nullptr) {
-        if (gpus > 1 || use_group) return render_scene_group(fname, stats);
-        CrHandle* h = nullptr;
-        int32_t rc = cr_create(device, &h);
-        if (rc != CR_OK) { fprintf(stderr, "Render failed. %s\n", cr_last_error(nullptr)); return rc; }
-        FlatScene f = flatten();
-        rc = cr_upload_scene(h, &f.desc);
-        if (rc == CR_OK) {
-            if (!is_movie) rc = render_image(h, fname, stats);
-            else {   // render_movie, scene/mod.rs:295-322 (the ffmpeg hand-off is out of scope)
-                if (mkdir(fname.c_str(), 0777) != 0 || mkdir((fname + "/artifacts").c_str(), 0777) != 0) rc = CR_ERR_IO;
-                size_t frames = compute_frame_count(), digits = std::to_string(frames).size();
-                // frame k is encoded and written by a helper thread while frame k+1 renders
-                // (two buffers; the reference formats and writes each frame before starting the next).
-                std::vector<double> bufs[2];
-                std::thread writers[2];
-                int32_t write_rc[2] = {CR_OK, CR_OK};
-                for (size_t fr = 0; rc == CR_OK && fr < frames; fr++) {
-                    const int slot = (int)(fr & 1);
-                    if (writers[slot].joinable()) { writers[slot].join(); if (write_rc[slot] != CR_OK) { rc = write_rc[slot]; break; } }
-                    std::string num = std::to_string(fr);
-                    num = std::string(digits - num.size(), '0') + num;
-                    rc = render_frame(h, bufs[slot], stats);
-                    if (rc != CR_OK) break;
-                    const std::string stem = fname + "/artifacts/image" + num;
-                    writers[slot] = std::thread([this, stem, slot, &bufs, &write_rc] { write_rc[slot] = write_frame(stem, bufs[slot]); });
-                    scene_cam.next_frame();
-                }
-                for (int k = 0; k < 2; k++) if (writers[k].joinable()) { writers[k].join(); if (rc == CR_OK) rc = write_rc[k]; }
-                if (rc == CR_OK) {   // scene/mod.rs:319 would run this
-                    std::string cmd;
-                    for (const std::string& a : mp4_command(fname, digits)) cmd += (cmd.empty() ? "" : " ") + (a.find_first_of("*()") != std::string::npos ? "'" + a + "'" : a);
-                    fprintf(stderr, "Frames written. To assemble the movie: %s\n", cmd.c_str());
+        timing = Timing();
+        const double t_begin = now_ms();
+        int32_t rc;
+        if (gpus > 1 || use_group) rc = render_scene_group(fname, stats);
+        else {
+            CrHandle* h = nullptr;
+            double t0 = now_ms();
+            rc = cr_create(device, &h);
+            timing.create_ms = now_ms() - t0;
+            if (rc != CR_OK) { fprintf(stderr, "Render failed. %s\n", cr_last_error(nullptr)); return rc; }
+            t0 = now_ms();
+            FlatScene f = flatten();
+            timing.flatten_ms = now_ms() - t0;
+            t0 = now_ms();
+            rc = cr_upload_scene(h, &f.desc);
+            timing.upload_ms = now_ms() - t0;
+            if (rc == CR_OK) {
+                if (!is_movie) { CrStats st; memset(&st, 0, sizeof st); rc = render_image(h, fname, &st); timing.kernel_ms = st.kernel_ms; timing.bvh_build_ms = std::max(0.0, st.upload_ms - timing.upload_ms); if (stats) *stats = st; }
+                else {   // render_movie, scene/mod.rs:295-322 (the ffmpeg hand-off is out of scope)
+                    if (mkdir(fname.c_str(), 0777) != 0 || mkdir((fname + "/artifacts").c_str(), 0777) != 0) rc = CR_ERR_IO;
+                    const size_t frames = compute_frame_count(), digits = std::to_string(frames).size();
+                    if (rc == CR_OK) rc = render_movie_frames(h, fname, 0, 1, frames, digits, stats, &timing);
+                    if (rc == CR_OK) print_mp4_command(fname, digits);
                 }
             }
+            if (rc != CR_OK) fprintf(stderr, "Render failed. %s\n", cr_last_error(h));
+            cr_destroy(h);
         }
-        if (rc != CR_OK) fprintf(stderr, "Render failed. %s\n", cr_last_error(h));
-        cr_destroy(h);
+        timing.total_ms = now_ms() - t_begin;
         return rc;
     }
 };

@@ -7,7 +7,9 @@
 // --bvh reference|sah|ordered|lbvh (the tree cr_upload_scene builds; reference = the parity mode, default), --refit (re-derive
 // the wrapper boxes per frame so keyframed primitives are not clipped; the reference does not),
 // --dump-desc FILE (write the flattened scene description and exit; used by the tests to check
-// this mirror against the Python one).
+// this mirror against the Python one), --sum-order reference|relaxed (CrRenderParams.sum_order; default: the library's),
+// --repeat N --timing (measurement: render_scene N times in this process, one JSON line of wall-clock phases each --
+// the shape of the reference's criterion benchmark, benches/renderer_benchmark.rs:16-42 -- the first is the cold one).
 #include "crucible.hpp"
 
 #include <cstdio>
@@ -41,8 +43,9 @@ int main(int argc, char** argv) {
     uint64_t seed = 0xC0FFEE, scene_seed = 1;
     int device = 0;
     std::string bvh = "reference", sky, format = "ppm";
-    bool refit = false, use_group = false;
-    int gpus = 1;
+    bool refit = false, use_group = false, timing = false;
+    int gpus = 1, repeat = 1;
+    std::string sum_order = "default";
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char* { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
@@ -64,6 +67,9 @@ int main(int argc, char** argv) {
         else if (a == "--refit") refit = true;
         else if (a == "--gpus") gpus = (int)strtol(next(), nullptr, 10);
         else if (a == "--group") use_group = true;
+        else if (a == "--timing") timing = true;
+        else if (a == "--repeat") repeat = std::max(1, atoi(next()));
+        else if (a == "--sum-order") sum_order = next();
         else if (a == "--dump-desc") dump = next();
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
@@ -107,11 +113,28 @@ int main(int argc, char** argv) {
         scene.gpus = std::max(1, gpus); scene.use_group = use_group;
         if (format != "ppm" && format != "p6" && format != "png") { fprintf(stderr, "--format takes ppm, p6 or png\n"); return 2; }
         scene.frame_format = format;
+        if (sum_order != "default" && sum_order != "reference" && sum_order != "relaxed") { fprintf(stderr, "--sum-order takes default, reference or relaxed\n"); return 2; }
+        scene.sum_order = sum_order == "reference" ? CR_SUM_REFERENCE_ORDER : (sum_order == "relaxed" ? CR_SUM_RELAXED : CR_SUM_DEFAULT);
         if (!dump.empty()) { dump_desc(scene.flatten(), dump.c_str()); return 0; }
-        CrStats st;
-        memset(&st, 0, sizeof st);
-        int32_t rc = scene.render_scene(file, &st);
-        if (rc == CR_OK) fprintf(stderr, "kernel %.3f ms, %.1f Msamples/s\n", st.kernel_ms, st.kernel_ms > 0 ? st.samples / st.kernel_ms / 1e3 : 0.0);
+        int32_t rc = CR_OK;
+        for (int rep = 0; rep < repeat && rc == CR_OK; rep++) {
+            CrStats st;
+            memset(&st, 0, sizeof st);
+            scene.scene_cam.frame = 0;
+            scene.quiet = timing;
+            rc = scene.render_scene(repeat > 1 ? file + (rep ? "_" + std::to_string(rep) : "") : file, &st);
+            if (rc == CR_OK && !timing) fprintf(stderr, "kernel %.3f ms, %.1f Msamples/s\n", st.kernel_ms, st.kernel_ms > 0 ? st.samples / st.kernel_ms / 1e3 : 0.0);
+            if (rc == CR_OK && timing) {
+                const Scene::Timing& t = scene.timing;
+                const double samples = (double)scene.scene_cam.image_width * scene.scene_cam.image_height * scene.scene_cam.samples * (movie ? (double)t.frames : 1.0);
+                printf("{\"run\": %d, \"width\": %u, \"height\": %u, \"samples\": %u, \"frames\": %zu, \"format\": \"%s\", \"real\": \"%s\", \"create_ms\": %.3f, \"flatten_ms\": %.3f, "
+                       "\"upload_ms\": %.3f, \"bvh_build_ms\": %.3f, \"render_ms\": %.3f, \"kernel_ms\": %.3f, \"write_ms\": %.3f, \"total_ms\": %.3f, \"msamples_per_s_end_to_end\": %.1f, "
+                       "\"msamples_per_s_kernel\": %.1f}\n",
+                       rep, scene.scene_cam.image_width, scene.scene_cam.image_height, scene.scene_cam.samples, movie ? t.frames : (size_t)1, format.c_str(), real.c_str(), t.create_ms,
+                       t.flatten_ms, t.upload_ms, t.bvh_build_ms, t.render_ms, t.kernel_ms, t.write_ms, t.total_ms, samples / t.total_ms / 1e3, t.kernel_ms > 0 ? samples / t.kernel_ms / 1e3 : 0.0);
+                fflush(stdout);
+            }
+        }
         return rc == CR_OK ? 0 : 1;
     } catch (const std::exception& e) {
         fprintf(stderr, "panic: %s\n", e.what());   // the reference panics here

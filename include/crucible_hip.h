@@ -52,7 +52,10 @@ enum {
     CR_ERR_IO = 5,            /* file open/write failed (reference: io::Error)        */
     CR_ERR_NAN = 6,           /* a pixel mean is NaN / outside [0,1]
                                  (reference: Color::new assert, src/utils.rs:345-350) */
-    CR_ERR_UNSUPPORTED = 7
+    CR_ERR_UNSUPPORTED = 7,
+    CR_ERR_PEER = 8           /* cr_group_*: another member of the group failed its render (every rank returns this or
+                                 its own error, none is left waiting in the collective), or an earlier collective of
+                                 this group failed and the group must be destroyed                               */
 };
 
 /* ---- scalar type the path computes in ---- */
@@ -430,7 +433,12 @@ CR_API int32_t cr_group_upload_scene(CrGroup* g, const CrSceneDesc* scene);
  * [0, samples) itself and returns the per-pixel MEAN.  d_out_rgb: device buffer of W*H*3 reals on the ROOT member's
  * device (member 0 = device_ids[0], or rank 0); other ranks may pass NULL.  Every rank of a rank-mode group must
  * call this with the same arguments (it is a collective).  Synchronous.  stats (may be NULL): counters summed over
- * the LOCAL members, kernel_ms = the slowest local member's render, reduce_ms in CrGroupStats. */
+ * the LOCAL members, kernel_ms = the slowest local member's render, reduce_ms in CrGroupStats.
+ * Failure: arguments are validated and buffers allocated on every member before anything is launched; with a
+ * collective, the members then agree (a 4-byte ncclAllReduce(min) on the render streams) that every render is fine
+ * before the ncclReduce is entered -- if one is not, EVERY rank returns an error (its own, or CR_ERR_PEER) and the
+ * group stays usable.  If a collective call itself fails, the group's communicators are aborted and every later call
+ * on it returns CR_ERR_PEER: destroy the group.  The calling thread's current HIP device is restored on return. */
 typedef struct CrGroupStats {
     CrStats render;        /* local members: counters summed, kernel_ms = max */
     double reduce_ms;      /* root-side time of the ncclReduce + the divide, HIP events on the root's stream */

@@ -193,3 +193,21 @@ def test_cli_refuses_malformed_radiance_files(cli, tmp_path):
         r = subprocess.run([cli, "--world", "5", "--sky", f, "--dump-desc", str(tmp_path / "o.bin")], cwd=ROOT, capture_output=True)
         assert r.returncode in (0, 101), (k, r.returncode, r.stderr[-200:])
         assert b"bad_alloc" not in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_timing_lines_and_sum_orders(cli, tmp_path):
+    """--repeat N --timing: one JSON line of wall-clock phases per render_scene call (the shape of the reference's criterion
+    benchmark); --sum-order picks CrRenderParams.sum_order, and both orders write the same P3 file here."""
+    import json
+    a, b = str(tmp_path / "ref"), str(tmp_path / "rel")
+    common = ["--world", "1", "--width", "96", "--samples", "6", "--real", "f64"]
+    r = subprocess.run([cli, "--file", a, "--sum-order", "reference", "--repeat", "2", "--timing"] + common, cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-300:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert [l["run"] for l in lines] == [0, 1] and all(l["width"] == 96 and l["height"] == 54 and l["samples"] == 6 for l in lines)
+    for l in lines:
+        assert l["total_ms"] >= l["render_ms"] + l["write_ms"] > 0 and l["kernel_ms"] > 0 and l["bvh_build_ms"] >= 0
+    env = dict(os.environ, CRUCIBLE_SUM_ORDER="reference")   # the flag wins over the environment
+    subprocess.check_call([cli, "--file", b, "--sum-order", "relaxed"] + common, cwd=ROOT, env=env)
+    assert open(a + ".ppm").read() == open(a + "_1.ppm").read() == open(b + ".ppm").read()

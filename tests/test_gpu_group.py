@@ -10,6 +10,7 @@ import pytest
 from crucible_amd import _abi as A
 from crucible_amd.demo_builder import book1_end_scene
 from crucible_amd.group import RenderGroup
+from crucible_amd.renderer import CrucibleError
 
 pytestmark = pytest.mark.gpu
 
@@ -106,5 +107,76 @@ def test_several_members_on_one_device(renderer, monkeypatch, rt, tag, members, 
         for k in COUNTERS:
             assert st[k] == sst[k], k      # the union of the shards is the 1-GPU sample set
         assert st["samples"] == 80 * 45 * spp
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("mode,failing", [("same-device-4", 2), ("same-device-4", 0), ("rank+rccl", 0), ("local+rccl", 0)])
+def test_a_failing_member_fails_the_whole_group_without_a_hang(monkeypatch, mode, failing):
+    """One member's render fails after it was launched (CRUCIBLE_GROUP_FAIL_MEMBER, a test hook): every member still
+    reaches the agreement step -- with a communicator, the 4-byte ncclAllReduce(min) on the render streams -- nobody
+    enters the ncclReduce, the call returns that member's error, and the SAME group renders correctly afterwards."""
+    import torch
+    sc = book1_end_scene(1, scene_seed=1, image_width=64, samples=8)
+    if mode.startswith("same-device"):
+        monkeypatch.setenv("CRUCIBLE_GROUP_SAME_DEVICE", "1")
+        g = RenderGroup.local([0] * 4)
+    else:
+        monkeypatch.setenv("CRUCIBLE_GROUP_FORCE_RCCL", "1")
+        g = RenderGroup.local([0]) if mode.startswith("local") else RenderGroup.rank(0, 0, 1, RenderGroup.unique_id())
+    try:
+        g.upload_scene(sc.flatten())
+        good, st = g.render(sc.scene_cam, seed=SEED, real_type=A.CR_REAL_F64)
+        monkeypatch.setenv("CRUCIBLE_GROUP_FAIL_MEMBER", str(failing))
+        torch.cuda.set_device(0)
+        with pytest.raises(CrucibleError) as e:
+            g.render(sc.scene_cam, seed=SEED, real_type=A.CR_REAL_F64)
+        assert e.value.code == A.CR_ERR_HIP and "injected" in str(e.value)
+        t = torch.zeros((sc.scene_cam.image_height, sc.scene_cam.image_width, 3), dtype=torch.float64, device="cuda:0")
+        with pytest.raises(CrucibleError):
+            g.render_device(sc.scene_cam, t.data_ptr(), seed=SEED, real_type=A.CR_REAL_F64)
+        monkeypatch.delenv("CRUCIBLE_GROUP_FAIL_MEMBER")
+        again, st2 = g.render(sc.scene_cam, seed=SEED, real_type=A.CR_REAL_F64)       # the group is still usable
+        assert np.array_equal(again, good) and all(st[k] == st2[k] for k in COUNTERS)
+    finally:
+        g.close()
+
+
+def test_group_argument_errors_are_found_before_anything_is_launched(monkeypatch):
+    """Bad arguments fail on every member identically, before a launch: no scene, a bad sample count, a missing output."""
+    monkeypatch.setenv("CRUCIBLE_GROUP_SAME_DEVICE", "1")
+    sc = book1_end_scene(1, scene_seed=1, image_width=32, samples=4)
+    g = RenderGroup.local([0, 0])
+    try:
+        with pytest.raises(CrucibleError) as e:
+            g.render(sc.scene_cam, seed=SEED)
+        assert e.value.code == A.CR_ERR_NO_SCENE
+        g.upload_scene(sc.flatten())
+        cd, p = sc.scene_cam.desc(), sc.scene_cam.params(SEED, A.CR_REAL_F64)
+        import ctypes as C
+        assert g.lib.cr_group_render(g.g, C.byref(cd), C.byref(p), None, None) == A.CR_ERR_INVALID_ARG       # root without an output buffer
+        assert g.lib.cr_group_render_host(g.g, C.byref(cd), C.byref(p), None, None) == A.CR_ERR_INVALID_ARG
+        p.samples = 0
+        out = np.zeros((sc.scene_cam.image_height, sc.scene_cam.image_width, 3))
+        assert g.lib.cr_group_render_host(g.g, C.byref(cd), C.byref(p), out.ctypes.data_as(C.c_void_p), None) == A.CR_ERR_INVALID_ARG
+        img, _ = g.render(sc.scene_cam, seed=SEED)
+        assert img.max() > 0
+    finally:
+        g.close()
+
+
+def test_group_calls_restore_the_callers_device(monkeypatch):
+    """The cr_group_* entry points visit every member's device; the calling thread's current device is restored."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    monkeypatch.setenv("CRUCIBLE_GROUP_SAME_DEVICE", "1")
+    sc = book1_end_scene(1, scene_seed=1, image_width=32, samples=4)
+    dev = C.c_int(-1)
+    assert hip.hipSetDevice(0) == 0
+    g = RenderGroup.local([0, 0])
+    try:
+        g.upload_scene(sc.flatten())
+        g.render(sc.scene_cam, seed=SEED)
+        assert hip.hipGetDevice(C.byref(dev)) == 0 and dev.value == 0
     finally:
         g.close()
