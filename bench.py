@@ -12,6 +12,12 @@ reduce issued inside the library (cr_group_render) and divided by 512 there -- a
 
 Rank 0 prints ONE JSON line.
 
+Summation order: the library default (CR_SUM_RELAXED: the same paths, attenuations multiplied in path order, samples added
+as 64-bit fixed point -- within 1e-12 of the reference order, equal work counters; include/crucible_hip.h).  The line
+carries the reference-order (bit-exact parity mode) rate of the same frame as `reference_order` and the largest
+per-channel difference between the two frames, measured on the device in this run.  `--sum-order reference` makes the
+parity mode the measured one.
+
 `roofline`: the path is a VALU-bound pointer-chasing walk (book1 lives in LDS), so the bound is
 the vector ALU.  achieved = ALGORITHMIC floating-point operations per launch / live kernel time, where the
 operation count is the reference algorithm's own arithmetic per unit of work (ALGO_FLOPS below: one IEEE add, sub, mul,
@@ -37,6 +43,22 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
 VALU_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.65}   # guide: 157.3 TFLOP/s f32 vector (FMA = 2); f64 vector is half rate
+# What the chip SUSTAINS on this pool (scripts/calib/valu_peak.hip, profiles/r03_valu_calib.txt): whatever the occupancy, a SIMD
+# retires one wave64 f64 add / mul / max per ~2.1 ns and one f32 add per ~1.2 ns (the clock drops as more waves issue), i.e.
+# 1024 SIMDs x 64 lanes / 2.1 ns = 31 T f64 operations/s without FMA -- the ceiling a non-fusing f64 kernel can reach.
+VALU_SUSTAINED_TOPS = {"f32": 1024 * 64 / 1.2e-9 / 1e12, "f64": 1024 * 64 / 2.1e-9 / 1e12}
+
+WHY_VALU = {
+    "book1": "book1 sits in LDS whole (tree, spheres, materials, f32 screening records): no global-memory read in the walk; HBM carries "
+             "24 bytes per pixel of sums; the vector ALU under lane divergence is what binds",
+    "teapot": "the 8191-wrapper tree is read through L2 below the 2048-wrapper LDS window (hit rate ~88 %): ~45 % of wave time waits on "
+              "dependent 32-byte fetches at 4 waves/SIMD, the rest is the vector ALU under lane divergence; HBM is idle",
+    "million": "1,048,575 wrappers: the walk makes ~80 box tests per segment, ~55 of them below the LDS window as dependent 32-byte "
+               "fetches through L2 / Infinity Cache (the 32 MB of screening records exceed an XCD's 4 MB L2): memory latency at 4 waves/SIMD "
+               "binds first, the vector ALU second; HBM bandwidth is not the bound",
+    "movie": "the teapot frame with a keyed camera (per-sample camera basis from the keyframes): as the teapot frame, plus ~100 f64 "
+             "operations per sample of camera set-up",
+}
 
 # Floating-point operations of the REFERENCE algorithm per unit of work (DESIGN.md section 4 derives each line):
 ALGO_FLOPS = {
@@ -160,6 +182,13 @@ def main():
     ap.add_argument("--bvh", choices=["reference", "sah", "ordered", "lbvh"], default="reference",
                     help="reference = the reference's median-split tree (parity mode, the headline); the others are the opt-in "
                          "trees of SURVEY 8(f) row 1 (extra lines, not the headline)")
+    ap.add_argument("--sum-order", choices=["default", "reference", "relaxed"], default="default",
+                    help="CrRenderParams.sum_order of the measured renders: default = the library's (relaxed sums); reference = the "
+                         "reference's own order of products and sums, bit for bit (the parity mode)")
+    ap.add_argument("--no-reference-line", action="store_true", help="skip the reference-order timing carried as `reference_order`")
+    ap.add_argument("--end-to-end", type=int, default=0, metavar="FRAMES",
+                    help="--workload movie: also render FRAMES consecutive frames (240 = all of configs[4]) with file output in P3, P6 "
+                         "and PNG, a writer thread encoding frame k while frame k+1 renders; reported as `end_to_end`")
     ap.add_argument("--force-group", action="store_true",
                     help="diagnostic: go through cr_group_render even with one GPU (with CRUCIBLE_GROUP_FORCE_RCCL=1 the one-rank RCCL "
                          "communicator and its reduce are exercised too)")
@@ -197,6 +226,8 @@ def main():
         return (A.CR_REAL_F32, torch.float32) if name == "f32" else (A.CR_REAL_F64, torch.float64)
 
     real_type, tdtype = real_of(args.real)
+    sum_order = {"default": A.CR_SUM_DEFAULT, "reference": A.CR_SUM_REFERENCE_ORDER, "relaxed": A.CR_SUM_RELAXED}[args.sum_order]
+    relaxed = args.sum_order == "relaxed" or (args.sum_order == "default" and os.environ.get("CRUCIBLE_SUM_ORDER") != "reference")
     seed, scene_seed = 0xC0FFEE, 1
     f32 = args.real == "f32"
     prim_bytes = 16 if f32 else 32
@@ -258,7 +289,7 @@ def main():
         reduce_how = "cr_group_render: ncclReduce(sum) of the per-pixel sums inside the library, divide on rank 0"
     r = None
     if group is None:
-        r = Renderer(dev_index)
+        r = Renderer(dev_index, sum_order=sum_order)
         r.upload_scene(flat)
     out = torch.empty((H, W, 3), dtype=tdtype, device=dev)
     step_no = [0]
@@ -266,7 +297,7 @@ def main():
     def step():
         """One render; returns the render kernels' time in ms (HIP events on the launch stream)."""
         if group is not None:
-            st = group.render_device(cam, out.data_ptr(), seed=seed, real_type=real_type)
+            st = group.render_device(cam, out.data_ptr(), seed=seed, real_type=real_type, sum_order=sum_order)
             return st["kernel_ms"]
         if frame_sharded:
             cam.frame = (step_no[0] * world + rank) % 240
@@ -287,7 +318,7 @@ def main():
 
     # one counted launch (untimed) for the work counters; also warms the build path
     if group is not None:
-        st = group.render_device(cam, out.data_ptr(), seed=seed, real_type=real_type)
+        st = group.render_device(cam, out.data_ptr(), seed=seed, real_type=real_type, sum_order=sum_order)
         st["bvh_entries"], st["scene_in_lds"] = None, None
     else:
         st = r.render_device(cam, out.data_ptr(), seed=seed, real_type=real_type, sample_begin=s_begin, sample_count=s_count,
@@ -327,6 +358,28 @@ def main():
                             "restatement only, ~29 % of pixels differ from the f64 image by more than 1e-4 (DESIGN.md section 2)"}
         del o32
 
+    # the reference's own order of products and sums (the bit-exact parity mode) on the same frame, and how far the measured
+    # frame is from it: largest per-channel difference, on the device
+    reference_line = None
+    if rank == 0 and world == 1 and relaxed and not args.no_reference_line and r is not None and not frame_sharded:
+        fast = torch.empty_like(out)
+        r.render_device(cam, fast.data_ptr(), seed=seed, real_type=real_type)
+        r.last_kernel_ms()
+        oref = torch.empty_like(out)
+        msr = []
+        for _ in range(3):
+            r.render_device(cam, oref.data_ptr(), seed=seed, real_type=real_type, sum_order=A.CR_SUM_REFERENCE_ORDER)
+            msr.append(r.last_kernel_ms())
+        str_ = r.render_device(cam, oref.data_ptr(), seed=seed, real_type=real_type, sum_order=A.CR_SUM_REFERENCE_ORDER, want_stats=True)
+        best = min(msr[1:])
+        reference_line = {"sum_order": "CR_SUM_REFERENCE_ORDER (innermost-first products, samples added in draw order: bit-equal to the oracle)",
+                          "value": round(W * H * spp / (best * 1e-3) / 1e6, 2), "unit": "Msamples/s", "kernel_ms": round(best, 3), "dtype": args.real,
+                          "max_abs_difference_of_the_measured_frame": float((fast - oref).abs().max().item()),
+                          "counters_equal": all(str_[k] == st[k] for k in ("segments", "node_tests", "prim_tests", "texel_fetches")),
+                          "note": "kernel time of the best of 2 renders after 1 warm-up (includes the ordered-sum kernel); needs a per-sample "
+                                  "colour buffer of W*H*spp*3 reals and a per-path attenuation stack"}
+        del fast, oref
+
     # the opt-in tree of SURVEY 8(f) row 1 on the same frame, carried as an extra key: the same image bit for bit
     # (checked here, on the device), fewer box tests.  The headline stays on the reference's own topology.
     optin_line = None
@@ -357,6 +410,49 @@ def main():
             r2.close()
         del ref_img
 
+    # configs[4] end to end: FRAMES consecutive frames of the movie through the boundary WITH their files, the way
+    # Scene::render_movie produces them (scene/mod.rs:295-322: render a frame, write it, next frame) -- except that a writer
+    # thread encodes and writes frame k while frame k+1 renders.  Render-only first, then one pass per format.
+    end_to_end = None
+    if rank == 0 and world == 1 and frame_sharded and args.end_to_end > 0 and r is not None:
+        import shutil
+        import tempfile
+        import threading
+        import numpy as np
+        nfr = args.end_to_end
+        host = [np.empty((H, W, 3), dtype=np.float64 if args.real == "f64" else np.float32) for _ in range(2)]
+        end_to_end = {"frames": nfr, "samples_per_frame": W * H * spp, "formats": {}}
+        t0 = time.perf_counter()
+        k_sum = 0.0
+        for fr in range(nfr):
+            cam.frame = fr % 240
+            _, stf = r.render(cam, seed=seed, real_type=real_type)
+            k_sum += stf["kernel_ms"]
+        t_render = time.perf_counter() - t0
+        end_to_end["render_only"] = {"wall_s": round(t_render, 3), "kernel_s": round(k_sum * 1e-3, 3),
+                                     "msamples_per_s": round(nfr * W * H * spp / t_render / 1e6, 1),
+                                     "what": "cr_render_host per frame (render + device->host copy + the Color::new check), no file"}
+        for fmt, ext in (("P3 (the reference's ASCII PPM)", ".ppm"), ("P6 (binary PPM)", ".p6.ppm"), ("PNG", ".png")):
+            tmp = tempfile.mkdtemp(prefix="crucible_e2e_")
+            writer, nbytes = None, 0
+            t0 = time.perf_counter()
+            for fr in range(nfr):
+                cam.frame = fr % 240
+                img, _ = r.render(cam, seed=seed, real_type=real_type)
+                if writer is not None:
+                    writer.join()
+                host[fr & 1][...] = img
+                path = os.path.join(tmp, f"image{fr:03d}{ext}")
+                writer = threading.Thread(target=r.write_image, args=(path, host[fr & 1]))
+                writer.start()
+            writer.join()
+            wall = time.perf_counter() - t0
+            nbytes = sum(os.path.getsize(os.path.join(tmp, f)) for f in os.listdir(tmp))
+            shutil.rmtree(tmp, ignore_errors=True)
+            end_to_end["formats"][fmt] = {"wall_s": round(wall, 3), "msamples_per_s": round(nfr * W * H * spp / wall / 1e6, 1),
+                                          "vs_render_only": round(wall / t_render, 4), "file_MB_per_frame": round(nbytes / nfr / 1e6, 2)}
+        cam.frame = 0
+
     if rank == 0:
         total_samples = W * H * spp * args.steps * (world if frame_sharded else 1)
         value = total_samples / elapsed / 1e6
@@ -366,9 +462,9 @@ def main():
         B = algorithmic_bytes(st, W, H, entry_bytes, prim_bytes)
         tflops = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         peak = VALU_PEAK_TFLOPS[args.real]
-        key = f"{args.workload}_{W}x{H}_spp{s_count}_{args.real}" + ("" if args.bvh == "reference" else "_" + args.bvh)
+        key = f"{args.workload}_{W}x{H}_spp{s_count}_{args.real}" + ("" if args.bvh == "reference" else "_" + args.bvh) + ("" if relaxed else "_reference_order")
         pmc, traffic = None, None
-        ppath = os.path.join(ROOT, "profiles", "r02_pmc.json")
+        ppath = os.path.join(ROOT, "profiles", "r03_pmc.json")
         if os.path.exists(ppath):
             try:
                 pmc = json.load(open(ppath)).get(key)
@@ -376,8 +472,23 @@ def main():
                 pmc = None
         if pmc:
             traffic = pmc["hbm_bytes"]
-            pmc = dict(pmc, from_committed_profile=f"profiles/r02_pmc.json[{key}] -- collected in separate rocprofv3 --pmc runs of this "
+            pmc = dict(pmc, from_committed_profile=f"profiles/r03_pmc.json[{key}] -- collected in separate rocprofv3 --pmc runs of this "
                                                    "workload, NOT measured in this run")
+        # which kernel ran, and what the compiler allocated for it (rocprofv3's arch_vgpr_count halves the allocation on gfx950)
+        b = lambda v: "true" if v else "false"
+        res_code = st["scene_in_lds"] if st["scene_in_lds"] is not None else 1
+        anim = flat.desc.n_keys > 0
+        cam_keyed = bool(cam.look_from_tl.keyframes() or cam.look_at_tl.keyframes())
+        screened = (not f32) and args.bvh != "ordered" and os.environ.get("CRUCIBLE_SCREEN", "1") != "0" and os.environ.get("CRUCIBLE_PIPELINE", "mega") == "mega" \
+            and not (res_code == 1 and os.environ.get("CRUCIBLE_SCREEN_LDS", "1") == "0")
+        kname = (f"cr::pathtrace_kernel<{'float' if f32 else 'double'}, {res_code}, {b(anim)}, {b(args.bvh == 'ordered')}, "
+                 f"{b(cam_keyed and not anim)}, {b(relaxed)}, {b(screened)}>")
+        resources = None
+        try:
+            resources = json.load(open(os.path.join(ROOT, "profiles", "r03_kernel_resources.json")))["kernels"].get(kname)
+        except Exception:
+            resources = None
+        sustained = VALU_SUSTAINED_TOPS[args.real]
         try:
             metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
         except Exception:
@@ -394,25 +505,39 @@ def main():
                                "ordered": "binned SAH topology walked near child first (CR_BVH_SAH_ORDERED; not the reference's tree or order)",
                                "lbvh": "Morton-code LBVH built on the device (CR_BVH_LBVH; not the reference's tree)"}[args.bvh],
                        "scene_residency": {0: "L2", 1: "whole scene in LDS", 2: "BVH top levels in LDS"}.get(st["scene_in_lds"]),
+                       "sum_order": ("CR_SUM_RELAXED (library default): path-order products, fixed-point per-pixel sums; within 1e-12 of the reference "
+                                     "order, equal work counters" if relaxed else
+                                     "CR_SUM_REFERENCE_ORDER: the reference's own order of products and sums, bit-equal to the oracle"),
+                       "box_tests": "f64 walk on f32 screening records, f64 test where f32 cannot decide (exact)" if screened else "in the scalar type",
                        "parallelism": ("1 GPU" + (" through cr_group_render" if group is not None else "")) if world == 1 else (f"frame-shard x{world}, no collective" if frame_sharded else
                                                                      f"spp-shard x{world}: {reduce_how}")},
             "roofline": {"bound": "valu", "achieved": round(tflops, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
                          "traffic": traffic,
-                         "kernel": "cr::pathtrace_kernel (kernel_ms also covers the ~2 ms ordered-sum kernel cr::sg_finalize_kernel)",
+                         "kernel": kname + (" (+ cr::fx_finalize_kernel, ~0.03 ms: fixed-point sums -> frame)" if relaxed else
+                                            " (+ cr::sg_finalize_kernel, the ordered sum)"),
+                         "kernel_resources": resources and dict(resources, source="profiles/r03_kernel_resources.json (compiler remarks of the "
+                                                                "same sources; not rocprofv3's halved arch_vgpr_count)"),
                          "kernel_ms": round(k_ms, 4),
                          "algorithmic_flops_per_launch": int(flops), "flops_per_unit": ALGO_FLOPS,
                          "peak_without_fma": peak / 2, "frac_of_peak_without_fma": round(tflops / (peak / 2), 4),
-                         "why_valu": "book1 is LDS-resident and the walk is branchy pointer chasing: HBM carries only the per-sample colours "
-                                     "and the attenuation stack; the vector ALU under lane divergence is what binds",
+                         "peak_sustained": round(sustained, 2), "frac_of_sustained": round(tflops / sustained, 4),
+                         "peak_sustained_note": "operations/s of the scalar type the chip sustains WITHOUT fusing, from scripts/calib/valu_peak.hip "
+                                                "(profiles/r03_valu_calib.txt): one wave64 f64 add/mul/max per ~2.1 ns per SIMD at any occupancy "
+                                                "(the clock drops to 1.0-1.4 GHz as more waves issue), f32 add ~1.2 ns",
+                         "why_valu": WHY_VALU[args.workload],
                          "counters_per_launch": {k: st[k] for k in ("samples", "segments", "node_tests", "prim_tests", "texel_fetches")},
                          "hbm": {"algorithmic_bytes_per_launch": int(B), "achieved_algorithmic_GBps": round(B / (k_ms * 1e-3) / 1e9, 2) if k_ms > 0 else None,
-                                 "peak_GBps": HBM_PEAK_GBS, "note": "SURVEY 8(d) byte model; exceeds the HBM peak because the scene is served from LDS -- "
+                                 "peak_GBps": HBM_PEAK_GBS, "note": "SURVEY 8(d) byte model; exceeds the HBM peak wherever the scene is served from LDS / L2 -- "
                                                                    "not a bound of this kernel",
                                  "measured_GBps_from_profile": round(traffic / (k_ms * 1e-3) / 1e9, 1) if traffic and k_ms > 0 else None,
                                  "probed_peak": hbm_probe()},
                          "executed": pmc},
             "kernel_msamples_per_s": round(W * H * s_count / (k_ms * 1e-3) / 1e6, 2) if k_ms > 0 else None,
         }
+        if end_to_end:
+            rec["end_to_end"] = end_to_end
+        if reference_line:
+            rec["reference_order"] = reference_line
         if f32_line:
             rec["f32_fast_mode"] = f32_line
         if optin_line:

@@ -1150,6 +1150,10 @@ template <typename real, int RES, bool ANIM, bool ORD, bool CAMK = false, bool R
 CR_D void pathtrace_body(const KernelArgs<real>& A) {
     using EntryT = typename EntryOf<real, ORD>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef CR_HOLD_VCC
+    unsigned long long vcc_hold;
+    asm volatile("s_mov_b64 %0, 0" : "={vcc}"(vcc_hold));
+#endif
     const Entry<real>* lds_entries = nullptr;
     const ScreenEntry* lds_screen = nullptr;
     const Prim<real>* prims = A.prims;
@@ -1445,6 +1449,9 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
                 atomicAdd(&c[12], __builtin_readcyclecounter() - d_begin);
             }
         })
+#ifdef CR_HOLD_VCC
+    asm volatile("" :: "{vcc}"(vcc_hold));
+#endif
     if (lane == 0) {
         atomicAdd((unsigned long long*)&A.counters[0], s0);
         atomicAdd((unsigned long long*)&A.counters[1], s1);
@@ -1453,9 +1460,18 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
 
     }
 }
+// The ~70 launch parameters are read where they are used, through the kernarg segment's own address (constant address
+// space: s_load, served by the scalar cache).  As a by-value parameter they were all loaded at kernel entry and stayed
+// live for the whole launch: the f64 kernel spilled 97 of them to VGPR lanes (230 v_readlane / v_writelane, 20 VGPRs
+// pushed to scratch); read this way it spills 6 (19, and 6).
+template <typename real> CR_D const KernelArgs<real>& kernel_args() {
+    return *(const KernelArgs<real>*)(const __attribute__((address_space(4))) KernelArgs<real>*)__builtin_amdgcn_kernarg_segment_ptr();
+}
 template <typename real, int RES, bool ANIM, bool ORD = false, bool CAMK = false, bool RELAX = false, bool SCREEN = false>
 __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const KernelArgs<real> A) {
-    pathtrace_body<real, RES, ANIM, ORD, CAMK, RELAX, SCREEN>(A);
+    // f32 kernels have registers to spare and lose 1 % to the reloads: they keep the by-value parameter
+    if constexpr (std::is_same<real, double>::value) pathtrace_body<real, RES, ANIM, ORD, CAMK, RELAX, SCREEN>(kernel_args<real>());
+    else pathtrace_body<real, RES, ANIM, ORD, CAMK, RELAX, SCREEN>(A);
 }
 
 // The same kernel compiled for 6 waves per SIMD (<= 80 VGPRs, 512-thread groups), for trees far larger than the

@@ -86,11 +86,11 @@ class RenderGroup:
     def upload_scene(self, flat):
         self._check(self.lib.cr_group_upload_scene(self.g, C.byref(flat.desc)))
 
-    def render(self, cam, *, seed, real_type=A.CR_REAL_F64):
+    def render(self, cam, *, seed, real_type=A.CR_REAL_F64, sum_order=A.CR_SUM_DEFAULT):
         """Collective: returns (image (H, W, 3) on the root -- zeros elsewhere --, stats dict)."""
         import numpy as np
         cd = cam.desc()
-        p = cam.params(seed, real_type)
+        p = cam.params(seed, real_type, sum_order=sum_order)
         out = np.zeros((cam.image_height, cam.image_width, 3), dtype=np.float64 if real_type == A.CR_REAL_F64 else np.float32)
         st = A.CrGroupStats()
         self._check(self.lib.cr_group_render_host(self.g, C.byref(cd), C.byref(p), out.ctypes.data_as(C.c_void_p), C.byref(st)))
@@ -98,10 +98,10 @@ class RenderGroup:
         d.update(reduce_ms=st.reduce_ms, members=st.members, used_rccl=st.used_rccl)
         return out, d
 
-    def render_device(self, cam, d_ptr, *, seed, real_type=A.CR_REAL_F64, want_stats=True):
+    def render_device(self, cam, d_ptr, *, seed, real_type=A.CR_REAL_F64, want_stats=True, sum_order=A.CR_SUM_DEFAULT):
         """Collective: the per-pixel mean lands in device memory at d_ptr on the root member's device."""
         cd = cam.desc()
-        p = cam.params(seed, real_type)
+        p = cam.params(seed, real_type, sum_order=sum_order)
         st = A.CrGroupStats()
         self._check(self.lib.cr_group_render(self.g, C.byref(cd), C.byref(p), C.c_void_p(d_ptr),
                                              C.byref(st) if want_stats else None))

@@ -11,19 +11,28 @@
 #define CHAIN8(OP)                                                                                              \
     OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
 
-enum Kind { FMA_F32, PK_FMA_F32, ADD_F32, MAX_F32, MAX3_F32, CNDMASK, ADD_U32, ADD_F64, MUL_F64, FMA_F64, MAX_F64, RCP_F64, SQRT_F32, N_KINDS };
+enum Kind { FMA_F32, PK_FMA_F32, ADD_F32, MAX_F32, MAX3_F32, CNDMASK, ADD_U32, ADD_F64, MUL_F64, FMA_F64, MAX_F64, RCP_F64, SQRT_F32,
+            CND_VCC_SET, CND_SGPR, CND_SGPR_ALT, MIN_F32, PK_ADD_F32, PK_MUL_F32, CND_E64_VCC, CMP_CND_VCC, CMP_CND_SGPR, CMP_VCC, CMP_SGPR, CMP_CND2_VCC, CMP_CND2_E64, N_KINDS };
 static const char* kind_name[N_KINDS] = {"v_fma_f32", "v_pk_fma_f32", "v_add_f32", "v_max_f32", "v_max3_f32", "v_cndmask_b32", "v_add_u32",
-                                         "v_add_f64", "v_mul_f64", "v_fma_f64", "v_max_f64", "v_rcp_f64", "v_sqrt_f32"};
+                                         "v_add_f64", "v_mul_f64", "v_fma_f64", "v_max_f64", "v_rcp_f64", "v_sqrt_f32",
+                                         "v_cndmask_b32(vcc written by v_cmp)", "v_cndmask_b32_e64(sgpr pair)", "v_cndmask_b32_e64(two sgpr pairs)", "v_min_f32", "v_pk_add_f32", "v_pk_mul_f32",
+                                         "v_cndmask_b32_e64(vcc)", "v_cmp_e32 vcc + v_cndmask_e32 (per pair)", "v_cmp_e64 sgpr + v_cndmask_e64 (per pair)", "v_cmp_lt_f32_e32 (vcc)", "v_cmp_lt_f32_e64 (sgpr pair)",
+                                         "v_cmp_e32 + 2 x v_cndmask_e32, an f64 select as compiled (per triple)", "v_cmp_e32 + 2 x v_cndmask_e64 vcc (per triple)"};
 
 template <int KIND>
 __global__ void __launch_bounds__(256) loop_kernel(unsigned long long* cycles, float* sink, int iters) {
-    float f[8]; double d[8]; unsigned u[8];
+    float f[8]; double d[8]; unsigned u[8], u2[8];
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p[8];
-    for (int i = 0; i < 8; i++) { f[i] = threadIdx.x + i; d[i] = threadIdx.x + i + 0.5; u[i] = threadIdx.x + i; p[i] = f2{f[i], f[i] + 1}; }
+    for (int i = 0; i < 8; i++) { f[i] = threadIdx.x + i; d[i] = threadIdx.x + i + 0.5; u[i] = threadIdx.x + i; u2[i] = threadIdx.x + 2 * i; p[i] = f2{f[i], f[i] + 1}; }
     const float b = 1.000001f, c = 0.5f;
     const double bd = 1.000001, cd = 0.5;
     const f2 bp = {b, b}, cp = {c, c};
+    const unsigned tid = threadIdx.x;
+    unsigned long long m0 = 0x5555555555555555ull, m1 = 0x0f0f0f0f0f0f0f0full;
+    asm volatile("s_mov_b64 %0, %0" : "+s"(m0));
+    asm volatile("s_mov_b64 %0, %0" : "+s"(m1));
+    if (KIND == CND_VCC_SET) asm volatile("v_cmp_gt_u32 vcc, 32, %0" :: "v"(tid) : "vcc");
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; it++) {
 #define OP_FMA_F32(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(b), "v"(c));
@@ -31,7 +40,21 @@ __global__ void __launch_bounds__(256) loop_kernel(unsigned long long* cycles, f
 #define OP_ADD_F32(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[i]) : "v"(c));
 #define OP_MAX_F32(i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(f[i]) : "v"(c));
 #define OP_MAX3_F32(i) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(c), "v"(b));
-#define OP_CND(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(threadIdx.x));
+#define OP_CND(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(tid));
+// Round 3: the 12.6-cycle v_cndmask_b32 of round 2 read a VCC that nothing in the kernel had ever written.  The variants below
+// select on a mask a v_cmp wrote first (VCC), on an SGPR pair, and alternately on two SGPR pairs.
+#define OP_CND_E64(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(u[i]) : "v"(tid), "s"(m0));
+#define OP_CND_E64_ALT(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(u[i]) : "v"(tid), "s"((i & 1) ? m1 : m0));
+#define OP_CND_E64_VCC(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(tid));
+#define OP_CMP_CND_VCC(i) asm volatile("v_cmp_lt_f32_e32 vcc, %1, %2\n\tv_cndmask_b32_e32 %0, %0, %3, vcc" : "+v"(u[i]) : "v"(f[i]), "v"(c), "v"(tid) : "vcc");
+#define OP_CMP_CND_SGPR(i) asm volatile("v_cmp_lt_f32_e64 %4, %1, %2\n\tv_cndmask_b32_e64 %0, %0, %3, %4" : "+v"(u[i]) : "v"(f[i]), "v"(c), "v"(tid), "s"(m0));
+#define OP_CMP_VCC(i) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" :: "v"(f[i]), "v"(c) : "vcc");
+#define OP_CMP_SGPR(i) asm volatile("v_cmp_lt_f32_e64 %2, %0, %1" :: "v"(f[i]), "v"(c), "s"(m0));
+#define OP_CMP_CND2_VCC(i) asm volatile("v_cmp_lt_f32_e32 vcc, %2, %3\n\tv_cndmask_b32_e32 %0, %0, %4, vcc\n\tv_cndmask_b32_e32 %1, %1, %4, vcc" : "+v"(u[i]), "+v"(u2[i]) : "v"(f[i]), "v"(c), "v"(tid) : "vcc");
+#define OP_CMP_CND2_E64(i) asm volatile("v_cmp_lt_f32_e32 vcc, %2, %3\n\tv_cndmask_b32_e64 %0, %0, %4, vcc\n\tv_cndmask_b32_e64 %1, %1, %4, vcc" : "+v"(u[i]), "+v"(u2[i]) : "v"(f[i]), "v"(c), "v"(tid) : "vcc");
+#define OP_MIN_F32(i) asm volatile("v_min_f32 %0, %0, %1" : "+v"(f[i]) : "v"(c));
+#define OP_PK_ADD(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(cp));
+#define OP_PK_MUL(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(bp));
 #define OP_ADD_U32(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
 #define OP_ADD_F64(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[i]) : "v"(cd));
 #define OP_MUL_F64(i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[i]) : "v"(bd));
@@ -52,12 +75,25 @@ __global__ void __launch_bounds__(256) loop_kernel(unsigned long long* cycles, f
             else if (KIND == FMA_F64) { CHAIN8(OP_FMA_F64) }
             else if (KIND == MAX_F64) { CHAIN8(OP_MAX_F64) }
             else if (KIND == RCP_F64) { CHAIN8(OP_RCP_F64) }
+            else if (KIND == CND_VCC_SET) { CHAIN8(OP_CND) }
+            else if (KIND == CND_SGPR) { CHAIN8(OP_CND_E64) }
+            else if (KIND == CND_SGPR_ALT) { CHAIN8(OP_CND_E64_ALT) }
+            else if (KIND == MIN_F32) { CHAIN8(OP_MIN_F32) }
+            else if (KIND == CND_E64_VCC) { CHAIN8(OP_CND_E64_VCC) }
+            else if (KIND == CMP_CND_VCC) { CHAIN8(OP_CMP_CND_VCC) }
+            else if (KIND == CMP_CND_SGPR) { CHAIN8(OP_CMP_CND_SGPR) }
+            else if (KIND == CMP_VCC) { CHAIN8(OP_CMP_VCC) }
+            else if (KIND == CMP_SGPR) { CHAIN8(OP_CMP_SGPR) }
+            else if (KIND == CMP_CND2_VCC) { CHAIN8(OP_CMP_CND2_VCC) }
+            else if (KIND == CMP_CND2_E64) { CHAIN8(OP_CMP_CND2_E64) }
+            else if (KIND == PK_ADD_F32) { CHAIN8(OP_PK_ADD) }
+            else if (KIND == PK_MUL_F32) { CHAIN8(OP_PK_MUL) }
             else { CHAIN8(OP_SQRT_F32) }
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     float s = 0;
-    for (int i = 0; i < 8; i++) s += f[i] + (float)d[i] + (float)u[i] + p[i].x + p[i].y;
+    for (int i = 0; i < 8; i++) s += f[i] + (float)d[i] + (float)u[i] + (float)u2[i] + p[i].x + p[i].y;
     sink[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) cycles[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
 }
@@ -114,6 +150,19 @@ int main(int argc, char** argv) {
     run<MAX_F64>(p.multiProcessorCount, d_cyc, d_sink, js, false);
     run<RCP_F64>(p.multiProcessorCount, d_cyc, d_sink, js, false);
     run<SQRT_F32>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<CND_VCC_SET>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<CND_SGPR>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<CND_SGPR_ALT>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<MIN_F32>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<PK_ADD_F32>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<PK_MUL_F32>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<CND_E64_VCC>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<CMP_CND_VCC>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<CMP_CND_SGPR>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<CMP_VCC>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<CMP_SGPR>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<CMP_CND2_VCC>(p.multiProcessorCount, d_cyc, d_sink, js, false);
+    run<CMP_CND2_E64>(p.multiProcessorCount, d_cyc, d_sink, js, false);
     if (js) { fprintf(js, "\n}\n"); fclose(js); }
     return 0;
 }

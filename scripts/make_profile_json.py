@@ -1,4 +1,4 @@
-"""profiles/r02_pmc.json from the rocprofv3 --pmc passes of scripts/profile_pmc.sh (gpurun_out/pmc_<TAG>/summary.txt).
+"""profiles/<round>_pmc.json (round = $ROUND, default r03) from the rocprofv3 --pmc passes of scripts/profile_pmc.sh (gpurun_out/pmc_<TAG>/summary.txt).
 
 usage: make_profile_json.py TAG KEY LAUNCHES_PER_RUN
   KEY               bench.py's profile key, e.g. book1_1920x1080_spp512_f64
@@ -19,6 +19,7 @@ several times, their counters are summed):
 import json, os, sys
 
 tag, key, per_run = sys.argv[1], sys.argv[2], float(sys.argv[3])
+R = os.environ.get("ROUND", "r03")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 text = open(os.path.join(root, "gpurun_out", "pmc_" + tag, "summary.txt")).read()
 sums, meta = {}, {}
@@ -48,11 +49,11 @@ rec = {
     "lds_busy": round(c["SQ_LDS_IDX_ACTIVE"] / (cycles * 256.0), 3), "lds_conflict_frac": round(c["SQ_LDS_BANK_CONFLICT"] / max(1.0, c["SQ_LDS_IDX_ACTIVE"]), 3),
     "FETCH_SIZE_KiB": c["FETCH_SIZE"], "WRITE_SIZE_KiB": c["WRITE_SIZE"], "hbm_bytes": int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
     "l2_hit_rate": round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3),
-    "source": f"rocprofv3 --pmc, one counter group per run (scripts/profile_pmc.sh TAG={tag}); summary kept as profiles/r02_pmc_{tag}.txt",
+    "source": f"rocprofv3 --pmc, one counter group per run (scripts/profile_pmc.sh TAG={tag}); summary kept as profiles/{R}_pmc_{tag}.txt",
 }
-out = os.path.join(root, "profiles", "r02_pmc.json")
+out = os.path.join(root, "profiles", f"{R}_pmc.json")
 data = json.load(open(out)) if os.path.exists(out) else {}
 data[key] = rec
 json.dump(data, open(out, "w"), indent=1)
-open(os.path.join(root, "profiles", f"r02_pmc_{tag}.txt"), "w").write(text)
+open(os.path.join(root, "profiles", f"{R}_pmc_{tag}.txt"), "w").write(text)
 print(key, json.dumps(rec, indent=1))

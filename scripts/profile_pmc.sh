@@ -10,7 +10,7 @@ WORKLOAD=${WORKLOAD:-book1}
 TAG=${TAG:-${WORKLOAD}_${REAL}}
 OUT=${GRAFT_REPO_ROOT:-$PWD}/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
-ARGS="bench.py --steps 1 --warmup 0 --spp $SPP --real $REAL --workload $WORKLOAD --no-cpu-baseline --no-f32-line --no-optin-line ${EXTRA_ARGS:-}"
+ARGS="bench.py --steps 1 --warmup 0 --spp $SPP --real $REAL --workload $WORKLOAD --no-cpu-baseline --no-f32-line --no-optin-line --no-reference-line ${EXTRA_ARGS:-}"
 pass() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 $ARGS > "$OUT/$name.log" 2>&1; echo "pass $TAG/$name rc=$?"; }
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM
 pass sq2 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM
