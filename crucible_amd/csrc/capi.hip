@@ -521,6 +521,18 @@ int32_t build_lbvh(CrHandle* h, const std::vector<Prim<real>>& src, const std::v
     return CR_OK;
 }
 
+// The f32 screening records of a (possibly refitted) f64 wrapper array, in the layout of the tree (ScreenEntry / ScreenEntryO).
+int32_t make_screen(CrHandle* h, DevScene<double>& ds, const void* entries, DevBuf& out) {
+    const size_t rec = ds.ordered ? sizeof(ScreenEntryO) : sizeof(ScreenEntry);
+    HIP_TRY(h, out.ensure((size_t)ds.n_entries * rec, ds.ordered ? entry_pad<ScreenEntryO>() : entry_pad<ScreenEntry>()));
+    const dim3 grid((unsigned)((ds.n_entries + 255) / 256));
+    if (ds.ordered) hipLaunchKernelGGL(screen_from_ordered_entries_kernel, grid, dim3(256), 0, h->stream, (const EntryO<double>*)entries, (ScreenEntryO*)out.p, ds.n_entries);
+    else hipLaunchKernelGGL(screen_from_entries_kernel, grid, dim3(256), 0, h->stream, (const Entry<double>*)entries, (ScreenEntry*)out.p, ds.n_entries);
+    HIP_TRY(h, hipGetLastError());
+    return CR_OK;
+}
+int32_t make_screen(CrHandle*, DevScene<float>&, const void*, DevBuf&) { return CR_OK; }
+
 template <typename real> int32_t build_dev_scene(CrHandle* h) {
     DevScene<real>& ds = dev_scene<real>(h);
     if (ds.built) return CR_OK;
@@ -854,11 +866,9 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     if constexpr (std::is_same<real, double>::value) {
-        if (!ds.ordered && ds.n_entries > 0) {   // the f32 screening records (pathtrace.hpp walk_round)
-            HIP_TRY(h, ds.screen.ensure((size_t)ds.n_entries * sizeof(ScreenEntry), entry_pad<ScreenEntry>()));
-            hipLaunchKernelGGL(screen_from_entries_kernel, dim3((unsigned)((ds.n_entries + 255) / 256)), dim3(256), 0, h->stream,
-                               (const Entry<double>*)ds.entries.p, (ScreenEntry*)ds.screen.p, ds.n_entries);
-            HIP_TRY(h, hipGetLastError());
+        if (ds.n_entries > 0) {   // the f32 screening records (pathtrace.hpp walk_round)
+            int32_t rc = make_screen(h, ds, ds.entries.p, ds.screen);
+            if (rc != CR_OK) return rc;
             HIP_TRY(h, hipStreamSynchronize(h->stream));
         } else ds.screen.release();
     }
@@ -1343,18 +1353,20 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     // per step), see walk_round (A/B in profiles/experiments/r03_screen_ab.txt).
     bool screen = false;
     if constexpr (std::is_same<real, double>::value) {
-        screen = h->pipeline == 0 && !ds.ordered && ds.screen.p != nullptr && ds.n_entries > 0 && h->screen_boxes;
+        screen = h->pipeline == 0 && ds.screen.p != nullptr && ds.n_entries > 0 && h->screen_boxes;
         if (screen) {
-            a.screen = (const ScreenEntry*)ds.screen.p;
+            a.screen = ds.screen.p;
             if (refit) {
-                HIP_TRY(h, ds.screen_refit.ensure((size_t)ds.n_entries * sizeof(ScreenEntry), ds.screen.pad));
-                hipLaunchKernelGGL(screen_from_entries_kernel, dim3((unsigned)((ds.n_entries + 255) / 256)), dim3(256), 0, h->stream,
-                                   (const Entry<double>*)ds.entries_refit.p, (ScreenEntry*)ds.screen_refit.p, ds.n_entries);
-                HIP_TRY(h, hipGetLastError());
-                a.screen = (const ScreenEntry*)ds.screen_refit.p;
+                int32_t rc = make_screen(h, ds, ds.entries_refit.p, ds.screen_refit);
+                if (rc != CR_OK) return rc;
+                a.screen = ds.screen_refit.p;
             }
         }
     }
+    // a SCREEN kernel stages screening records where the others stage wrappers
+    const size_t screen_rec = ds.ordered ? sizeof(ScreenEntryO) : sizeof(ScreenEntry);
+    auto r16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t lds_all_screen = ds.lds_bytes - r16((size_t)ds.n_entries * ds.entry_bytes) + r16((size_t)ds.n_entries * screen_rec);
     a.tiles_x = (uint32_t)(c.W + 7) / 8u; a.tiles_y = (uint32_t)(c.H + 7) / 8u;
     a.work_counter = (uint32_t*)h->work_counter.p;
     a.counters = (uint64_t*)h->counters.p;
@@ -1370,22 +1382,30 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     const int sum_order = p->sum_order == CR_SUM_DEFAULT ? (h->pipeline == 0 ? h->default_sum_order : CR_SUM_REFERENCE_ORDER) : p->sum_order;
     if (sum_order == CR_SUM_RELAXED && h->pipeline != 0) return fail(h, CR_ERR_UNSUPPORTED, "CR_SUM_RELAXED is implemented by the megakernel pipeline only");
     const bool relax = sum_order == CR_SUM_RELAXED;
+    const size_t fx_need = relax ? fx_lds_bytes(MaxBlock<real>::value, 4) : 0;   // the relaxed sums' slots share the LDS
+    const bool screen_lds = screen && h->screen_lds && lds_all_screen + fx_need <= h->lds_limit;
+    const bool plain_lds = ds.lds_bytes + fx_need <= h->lds_limit;
     if (ds.ordered) {   // near-child-first walk: megakernel only
         if (h->pipeline != 0) return fail(h, CR_ERR_UNSUPPORTED, "CR_BVH_SAH_ORDERED is implemented by the megakernel pipeline only");
-        if (ds.n_entries > 0 && ds.lds_bytes <= h->lds_limit) {
+        constexpr bool f32 = std::is_same<real, float>::value;   // the double kernel needs far more than 80 VGPRs: it halves there
+        if (ds.n_entries > 0 && (plain_lds || screen_lds)) {
             a.lds_entries = ds.n_entries;
+            if constexpr (!f32) if (screen_lds) return launch_variant<real, RES_LDS, true, false, true>(h, a, lds_all_screen, stats, anim, cam_keys, relax);
+            a.screen = nullptr;
             return launch_variant<real, RES_LDS, true, false>(h, a, ds.lds_bytes, stats, anim, cam_keys, relax);
         }
-        constexpr bool f32 = std::is_same<real, float>::value;   // the double kernel needs far more than 80 VGPRs: it halves there
         const bool latency = f32 && h->latency_entries > 0 && ds.n_entries > h->latency_entries;
-        const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, (latency ? h->latency_top_bytes : h->lds_top_bytes) / sizeof(EntryO<real>));
+        const size_t window_rec = screen ? sizeof(ScreenEntryO) : sizeof(EntryO<real>);
+        const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, (latency ? h->latency_top_bytes : h->lds_top_bytes) / window_rec);
         if (top > 0) {
             a.lds_entries = top;
-            const size_t bytes = (size_t)top * sizeof(EntryO<real>);
+            const size_t bytes = (size_t)top * window_rec;
             if constexpr (f32) if (latency) return launch_variant<real, RES_TOP, true, true>(h, a, bytes, stats, anim, cam_keys, relax);
+            if constexpr (!f32) if (screen) return launch_variant<real, RES_TOP, true, false, true>(h, a, bytes, stats, anim, cam_keys, relax);
             return launch_variant<real, RES_TOP, true, false>(h, a, bytes, stats, anim, cam_keys, relax);
         }
         a.lds_entries = 0;
+        if constexpr (!f32) if (screen) return launch_variant<real, RES_GLOBAL, true, false, true>(h, a, 0, stats, anim, cam_keys, relax);
         return launch_variant<real, RES_GLOBAL, true, false>(h, a, 0, stats, anim, cam_keys, relax);
     }
     if (h->pipeline == 1) return render_wavefront<real>(h, a, ds, anim || cam_keys, stats);
@@ -1402,14 +1422,10 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
             return (anim || cam_keys) ? launch_queue<real, RES_TOP, true>(h, a, bytes, stats) : launch_queue<real, RES_TOP, false>(h, a, bytes, stats);
         }
     }
-    if (ds.n_entries > 0 && ds.lds_bytes <= h->lds_limit) {
+    if (ds.n_entries > 0 && (plain_lds || screen_lds)) {
         a.lds_entries = ds.n_entries;
-        if constexpr (std::is_same<real, double>::value) {   // screening records beside the scene, when both (and the relaxed sums' slots) fit
-            const size_t sb = ((size_t)ds.n_entries * sizeof(ScreenEntry) + 15) & ~(size_t)15;
-            if (screen && h->screen_lds && ds.lds_bytes + sb + fx_lds_bytes(MaxBlock<real>::value, 4) <= std::min(h->lds_limit, (size_t)160 * 1024))
-                return launch_variant<real, RES_LDS, false, false, true>(h, a, ds.lds_bytes + sb, stats, anim, cam_keys, relax);
-            a.screen = nullptr;
-        }
+        if constexpr (std::is_same<real, double>::value) if (screen_lds) return launch_variant<real, RES_LDS, false, false, true>(h, a, lds_all_screen, stats, anim, cam_keys, relax);
+        a.screen = nullptr;
         return launch_variant<real, RES_LDS, false, false>(h, a, ds.lds_bytes, stats, anim, cam_keys, relax);
     }
     constexpr bool f32 = std::is_same<real, float>::value;   // the double kernel needs far more than 80 VGPRs: it halves there

@@ -174,6 +174,15 @@ struct alignas(16) ScreenEntry {
     int32_t skip;
     int32_t leaf;
 };
+// ... and of an EntryO (CR_BVH_SAH_ORDERED): 64 bytes instead of 96.
+struct alignas(16) ScreenEntryO {
+    float b[6];
+    int32_t unused;
+    int32_t leaf;
+    int32_t skip[8];
+};
+template <bool ORD> struct ScreenOf { using type = ScreenEntry; };
+template <> struct ScreenOf<true> { using type = ScreenEntryO; };
 constexpr int32_t kLeafRun = 0x40000000;
 constexpr int32_t kLeafPseudo = 0x20000000;   // with kLeafRun: the record stands for a primitive / list that BVHWrapper::hit tests without a box
 constexpr int32_t kLeafRunIndex = 0x1fffffff;
@@ -229,7 +238,7 @@ template <typename real> struct KernelArgs {
     const Key<real>* keys;
     const Key<real>* cam_keys;   // this launch's camera keyframes (look_from keys, then look_at keys)
     const int32_t* leaf_runs;    // (first, count) pairs for the leaves flagged kLeafRun
-    const ScreenEntry* screen;   // f64, unordered trees: one screening record per wrapper (null: every test in f64)
+    const void* screen;          // f64 SCREEN kernels: one screening record per wrapper (ScreenEntry, or ScreenEntryO for an ordered tree)
     int32_t n_entries, n_prims, n_mats, n_texs;
     int32_t lds_entries;      // entries staged in LDS (all of them, or the top levels of a large tree)
     int32_t lds_side;         // RES_TOP: materials and textures follow the entry window in LDS (they are small even when
@@ -950,6 +959,24 @@ CR_D ScreenEntry fetch_screen(const ScreenEntry* lds, const ScreenEntry* glob, i
     return glob[idx];
 }
 
+// The ordered layout's screening record read into the same shape: skip = the link of the ray's octant.
+template <int RES>
+CR_D ScreenEntry fetch_screen_ordered(const ScreenEntryO* lds, const ScreenEntryO* glob, int32_t lds_n, int32_t idx, int32_t oct) {
+    ScreenEntry e;
+    if (RES == RES_LDS || (RES == RES_TOP && idx < lds_n)) {
+        const ScreenEntryO* s = lds + idx;
+        LdsPtr<float> b = (LdsPtr<float>)s->b;
+        for (int k = 0; k < 6; k++) e.b[k] = b[k];
+        e.leaf = *(LdsPtr<int32_t>)&s->leaf; e.skip = ((LdsPtr<int32_t>)s->skip)[oct];
+    } else {
+        const ScreenEntryO* s = glob + idx;
+        GlobPtr<float> b = (GlobPtr<float>)s->b;
+        for (int k = 0; k < 6; k++) e.b[k] = b[k];
+        e.leaf = *(GlobPtr<int32_t>)&s->leaf; e.skip = ((GlobPtr<int32_t>)s->skip)[oct];
+    }
+    return e;
+}
+
 // The per-ray state of BVHWrapper::hit's walk, kept in registers so a walk can be suspended and resumed.
 template <typename real> struct WalkState {
     V3<real> inv;        // 1 / direction
@@ -999,12 +1026,13 @@ template <typename real> CR_D void walk_begin(WalkState<real>& w, V3<real> rd) {
 template <typename real, int RES, bool ANIM, bool ORD = false, bool SCREEN = false>
 CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, const Prim<real>* prims, V3<real> ro, V3<real> rd, real rtime,
                      WalkState<real>& w, bool walking, uint32_t budget, unsigned long long& c_node, uint32_t& c_prim, Diag* dg = nullptr,
-                     const ScreenEntry* lds_screen = nullptr) {
-    static_assert(!SCREEN || (std::is_same<real, double>::value && !ORD), "screening records: f64, unordered trees");
+                     const void* lds_screen = nullptr) {
+    static_assert(!SCREEN || std::is_same<real, double>::value, "screening records exist for the f64 kernels");
     const real tmin = real(0.001);
     const int32_t n_entries = A.n_entries;
-    // RES_TOP with screening: the LDS window holds screening records, every f64 record is read from global memory
-    const int32_t lds_n64 = (SCREEN && RES == RES_TOP) ? 0 : A.lds_entries;
+    // SCREEN kernels keep only screening records in LDS: the rare f64 record is read from global memory
+    constexpr int RES64 = SCREEN ? RES_GLOBAL : RES;
+    const int32_t lds_n64 = SCREEN ? 0 : A.lds_entries;
     int32_t leaf = -1;
     if (walking) {
         CR_DIAG_HIT(dg, DG_ROUND_WAVE, DG_ROUND_LANE);
@@ -1032,7 +1060,8 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
                 uint32_t nodes = 0;
                 // `it` is the same in every lane still in the loop (a scalar register)
                 for (uint32_t it = 0; w.idx < n_entries; it++) {
-                    const ScreenEntry se = fetch_screen<RES>(lds_screen, A.screen, A.lds_entries, w.idx);
+                    const ScreenEntry se = ORD ? fetch_screen_ordered<RES>((const ScreenEntryO*)lds_screen, (const ScreenEntryO*)A.screen, A.lds_entries, w.idx, w.oct)
+                                               : fetch_screen<RES>((const ScreenEntry*)lds_screen, (const ScreenEntry*)A.screen, A.lds_entries, w.idx);
                     const Pair<float> tx = (Pair<float>{se.b[0], se.b[1]} - fox) * fix;
                     const Pair<float> ty = (Pair<float>{se.b[2], se.b[3]} - foy) * fiy;
                     const Pair<float> tz = (Pair<float>{se.b[4], se.b[5]} - foz) * fiz;
@@ -1047,11 +1076,12 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
                     bool miss = d < 0.0f;
                     if (__builtin_expect(!(__builtin_fabsf(d) > th), 0)) {   // too close to call in f32: Aabb::hit in f64 on the f64 box
                         CR_DIAG_HIT(dg, DG_BAND_WAVE, DG_BAND_LANE);
-                        const Entry<real> e = fetch_entry<real, RES>(lds_entries, A.entries, lds_n64, w.idx);
+                        const Entry<real> e = ORD ? fetch_entry_ordered<real, RES64>(lds_entries, A.entries, lds_n64, w.idx, w.oct)
+                                                  : fetch_entry<real, RES64>(lds_entries, A.entries, lds_n64, w.idx);
                         miss = !box_hit(e.b, ro, w.inv, tmin, w.best_t);
                     }
                     const bool inner = se.leaf < 0;
-                    w.idx = (inner && !miss) ? -se.leaf : se.skip;
+                    w.idx = (inner && !miss) ? (ORD ? ordered_near(se.leaf, w.oct) : -se.leaf) : se.skip;
                     if (!(miss || inner)) { leaf = se.leaf; break; }
                     if (it + 1 == budget) break;
                 }
@@ -1064,8 +1094,8 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
             const real tmax = w.best_t;
             uint32_t nodes = 0;
             for (uint32_t it = 0; w.idx < n_entries; it++) {
-                const Entry<real> e = ORD ? fetch_entry_ordered<real, RES>(lds_entries, A.entries, lds_n64, w.idx, w.oct)
-                                          : fetch_entry<real, RES>(lds_entries, A.entries, lds_n64, w.idx);
+                const Entry<real> e = ORD ? fetch_entry_ordered<real, RES64>(lds_entries, A.entries, lds_n64, w.idx, w.oct)
+                                          : fetch_entry<real, RES64>(lds_entries, A.entries, lds_n64, w.idx);
                 nodes++;
                 CR_DIAG_HIT(dg, DG_BOX_WAVE, DG_BOX_LANE);
                 const bool miss = box_miss_fast(e.b, ox, oy, oz, ix, iy, iz, tmin, tmax);
@@ -1077,8 +1107,8 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
             c_node += nodes;
         }
         for (; exact_steps != 0u && w.idx < n_entries; exact_steps--) {
-            const Entry<real> e = ORD ? fetch_entry_ordered<real, RES>(lds_entries, A.entries, lds_n64, w.idx, w.oct)
-                                      : fetch_entry<real, RES>(lds_entries, A.entries, lds_n64, w.idx);
+            const Entry<real> e = ORD ? fetch_entry_ordered<real, RES64>(lds_entries, A.entries, lds_n64, w.idx, w.oct)
+                                      : fetch_entry<real, RES64>(lds_entries, A.entries, lds_n64, w.idx);
             c_node++;
             bool hit = box_hit(e.b, ro, w.inv, tmin, w.best_t);
             w.idx = (hit && e.leaf < 0) ? (ORD ? ordered_near(e.leaf, w.oct) : -e.leaf) : e.skip;
@@ -1155,7 +1185,7 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
     asm volatile("s_mov_b64 %0, 0" : "={vcc}"(vcc_hold));
 #endif
     const Entry<real>* lds_entries = nullptr;
-    const ScreenEntry* lds_screen = nullptr;
+    const void* lds_screen = nullptr;
     const Prim<real>* prims = A.prims;
     const Mat<real>* mats = A.mats;
     const Tex<real>* texs = A.texs;
@@ -1165,14 +1195,14 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
             uint32_t* d = (uint32_t*)(smem + off);
             for (size_t i = threadIdx.x; i < bytes / 4; i += blockDim.x) d[i] = s[i];
         };
-        // RES_TOP with screening records: the window holds those (twice as many wrappers in the same bytes)
-        constexpr bool screen_window = SCREEN && RES == RES_TOP;
-        const size_t window_rec = screen_window ? sizeof(ScreenEntry) : sizeof(EntryT);
-        copy(screen_window ? (const void*)A.screen : (const void*)A.entries, 0, (size_t)A.lds_entries * window_rec);
+        // SCREEN kernels stage the f32 screening records instead of the f64 wrappers (twice as many wrappers in the same bytes)
+        using ScreenT = typename ScreenOf<ORD>::type;
+        constexpr size_t window_rec = SCREEN ? sizeof(ScreenT) : sizeof(EntryT);
+        copy(SCREEN ? A.screen : (const void*)A.entries, 0, (size_t)A.lds_entries * window_rec);
         lds_entries = (const Entry<real>*)smem;
-        if (screen_window) lds_screen = (const ScreenEntry*)smem;
+        if (SCREEN) lds_screen = (const void*)smem;
         if (RES == RES_LDS) {   // the whole scene: entries | prims | mats | texs, each 16-B aligned
-            size_t o1 = (((size_t)A.n_entries * sizeof(EntryT) + 15) & ~(size_t)15);
+            size_t o1 = (((size_t)A.n_entries * window_rec + 15) & ~(size_t)15);
             size_t o2 = o1 + (((size_t)A.n_prims * sizeof(Prim<real>) + 15) & ~(size_t)15);
             size_t o3 = o2 + (((size_t)A.n_mats * sizeof(Mat<real>) + 15) & ~(size_t)15);
             copy(A.prims, o1, (size_t)A.n_prims * sizeof(Prim<real>));
@@ -1181,11 +1211,6 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
             prims = (const Prim<real>*)(smem + o1);
             mats = (const Mat<real>*)(smem + o2);
             texs = (const Tex<real>*)(smem + o3);
-            if constexpr (SCREEN) {   // ... | screening records
-                size_t o4 = o3 + (((size_t)A.n_texs * sizeof(Tex<real>) + 15) & ~(size_t)15);
-                copy(A.screen, o4, (size_t)A.n_entries * sizeof(ScreenEntry));
-                lds_screen = (const ScreenEntry*)(smem + o4);
-            }
         } else if (A.lds_side) {   // RES_TOP: entry window | mats | texs
             size_t o2 = (((size_t)A.lds_entries * window_rec + 15) & ~(size_t)15);
             size_t o3 = o2 + (((size_t)A.n_mats * sizeof(Mat<real>) + 15) & ~(size_t)15);
@@ -1494,6 +1519,17 @@ __global__ void __launch_bounds__(256) screen_from_entries_kernel(const Entry<do
     ScreenEntry o;
     for (int k = 0; k < 6; k++) o.b[k] = (float)v.b[k];
     o.skip = v.skip; o.leaf = v.leaf;
+    s[i] = o;
+}
+
+__global__ void __launch_bounds__(256) screen_from_ordered_entries_kernel(const EntryO<double>* e, ScreenEntryO* s, int32_t n) {
+    const int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const EntryO<double> v = e[i];
+    ScreenEntryO o;
+    for (int k = 0; k < 6; k++) o.b[k] = (float)v.b[k];
+    o.unused = 0; o.leaf = v.leaf;
+    for (int k = 0; k < 8; k++) o.skip[k] = v.skip[k];
     s[i] = o;
 }
 
