@@ -1,5 +1,6 @@
 """Seeded random scenes beyond the committed ones (tests/test_gpu_fuzz.py's generator), HIP library vs oracle: images and
-counters must be equal.  usage: fuzz_campaign.py FIRST_SEED COUNT [lists] [wrappers] [hostile|big|camera]   -- prints one line per mismatch and a summary.
+counters must be equal in the parity mode (CR_SUM_REFERENCE_ORDER); the library default (CR_SUM_RELAXED) is rendered too and must
+have the same counters, the same NaN verdict and a frame within 1e-12 (f64) / n_samples * 2^-22 (f32).  usage: fuzz_campaign.py FIRST_SEED COUNT [lists] [wrappers] [hostile|big|camera]   -- prints one line per mismatch and a summary.
 Test infrastructure (it imports the oracle); not part of the product."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,12 +36,29 @@ for seed in range(first, first + count):
         try:
             r.upload_scene(sc.flatten())
             try:
-                img, st = r.render(sc.scene_cam, seed=seed, real_type=rt)
+                img, st = r.render(sc.scene_cam, seed=seed, real_type=rt, sum_order=A.CR_SUM_REFERENCE_ORDER)
                 gpu_nan = False
             except Exception as e:
                 if getattr(e, "code", None) != A.CR_ERR_NAN:
                     raise
                 gpu_nan = True
+            try:
+                fast, fst = r.render(sc.scene_cam, seed=seed, real_type=rt, sum_order=A.CR_SUM_RELAXED)
+                fast_nan = False
+            except Exception as e:
+                if getattr(e, "code", None) != A.CR_ERR_NAN:
+                    raise
+                fast_nan = True
+            if fast_nan != gpu_nan:
+                bad += 1; print(f"MISMATCH seed {seed} rt {rt}: NaN verdict relaxed={fast_nan} reference order={gpu_nan}", flush=True)
+            elif not gpu_nan:
+                tol = 1e-12 if rt == A.CR_REAL_F64 else sc.scene_cam.samples * 2.0 ** -22
+                d = float(np.abs(fast.astype(np.float64) - img.astype(np.float64)).max()) if img.size else 0.0
+                if not d <= tol:
+                    bad += 1; print(f"MISMATCH seed {seed} rt {rt} variant {variant}: relaxed frame off by {d}", flush=True)
+                for k in COUNTERS:
+                    if fst[k] != st[k]:
+                        bad += 1; print(f"MISMATCH seed {seed} rt {rt} variant {variant}: relaxed counter {k} {fst[k]} vs {st[k]}", flush=True)
             tree = r.export_bvh(rt) if variant == 2 else None
             empty = tree is not None and len(tree[1]) == 0   # no visible primitive: the opt-in trees have no wrapper at all
             if empty:
