@@ -175,6 +175,33 @@ def test_ppm_writer_and_quantiser(hiplib, tmp_path):
     assert q.tolist() == [[0, 0, 255]]                       # `as u32` saturates, NaN -> 0; 255*sqrt(2) = 360 -> byte clamp
 
 
+def test_ppm_writer_formats_whole_frames_in_chunks(hiplib, tmp_path):
+    """The P3 writer formats 65536 pixels at a time into memory (one fprintf per pixel took as long as rendering the frame): a frame that is
+    no multiple of the chunk, every byte value, and channels no Color could hold (> 1: printed as `as u32` would, not clamped; NaN and
+    negatives: 0) must come out as the line-by-line `writeln!(file, "{color}")` of camera/mod.rs:306-311 would."""
+    rs = np.random.RandomState(11)
+    w, h = 517, 331                                     # 171127 pixels: two full chunks and a ragged one
+    img = rs.uniform(0, 1, size=(h, w, 3))
+    img.reshape(-1)[:256] = (np.arange(256) / 255.0) ** 2 * (1 + 1e-12)     # every byte value, just above its boundary
+    img[5, 7] = (4.0, 1e12, 1e300)                      # 510, 255000000, u32::MAX (saturating cast)
+    img[6, 7] = (np.nan, -0.5, -0.0)
+    for dtype, rt in ((np.float64, A.CR_REAL_F64), (np.float32, A.CR_REAL_F32)):
+        with np.errstate(over="ignore"):
+            a = np.ascontiguousarray(img.astype(dtype))    # 1e300 -> inf in f32
+        path = str(tmp_path / f"big_{rt}.ppm")
+        assert hiplib.cr_write_ppm(path.encode(), a.ctypes.data_as(C.c_void_p), rt, w, h) == A.CR_OK
+        lines = open(path).read().split("\n")
+        assert lines[:3] == ["P3", f"{w} {h}", "255"] and lines[-1] == "" and len(lines) == 3 + w * h + 1
+        with np.errstate(invalid="ignore", over="ignore"):
+            v = 255.0 * np.sqrt(a.astype(np.float64).reshape(-1, 3))
+        v = np.where(np.isnan(v) | (v <= 0), 0.0, np.minimum(v, 4294967295.0))
+        expect = v.astype(np.uint64)
+        got = np.array([l.split() for l in lines[3:-1]], dtype=np.uint64)
+        assert np.array_equal(got, expect)
+        assert lines[3 + 5 * w + 7] == ("510 255000000 4294967295" if dtype == np.float64 else lines[3 + 5 * w + 7])
+        assert lines[3 + 6 * w + 7] == "0 0 0"
+
+
 def test_png_and_binary_ppm_carry_the_same_bytes(hiplib, tmp_path):
     """P6 and PNG output quantise exactly like the P3 writer."""
     from PIL import Image
