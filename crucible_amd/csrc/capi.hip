@@ -134,6 +134,8 @@ struct CrHandle {
     size_t latency_top_bytes = 48 * 1024;
     size_t lds_side_limit = 16 * 1024;   // RES_TOP: materials + textures join the LDS window up to this size (CRUCIBLE_LDS_SIDE_KB; 0 = never)
     size_t lds_top_bytes = 64 * 1024;   // LDS spent on the top of a tree that does not fit whole (CRUCIBLE_LDS_TOP_KB; 0 = none)
+    size_t lds_top_bytes_screen = 128 * 1024;   // ... by the f64 SCREEN kernels (4096 screening records: one workgroup per CU has the LDS to itself; teapot +2.5 %)
+    bool lds_top_set = false;           // CRUCIBLE_LDS_TOP_KB given: it applies to every kernel
     int blocks_per_cu_override = 0;
     int block_override = 0;
     // Wave scheduling of the walk (speed only).  -1 = chosen per scene: sphere scenes 10 / 56, scenes with triangles 8 / 40 --
@@ -1396,7 +1398,7 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
         }
         const bool latency = f32 && h->latency_entries > 0 && ds.n_entries > h->latency_entries;
         const size_t window_rec = screen ? sizeof(ScreenEntryO) : sizeof(EntryO<real>);
-        const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, (latency ? h->latency_top_bytes : h->lds_top_bytes) / window_rec);
+        const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, (latency ? h->latency_top_bytes : (screen && !h->lds_top_set ? h->lds_top_bytes_screen : h->lds_top_bytes)) / window_rec);
         if (top > 0) {
             a.lds_entries = top;
             const size_t bytes = (size_t)top * window_rec;
@@ -1431,7 +1433,7 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     constexpr bool f32 = std::is_same<real, float>::value;   // the double kernel needs far more than 80 VGPRs: it halves there
     const bool latency = f32 && h->latency_entries > 0 && ds.n_entries > h->latency_entries;
     const size_t window_rec = screen ? sizeof(ScreenEntry) : sizeof(Entry<real>);   // a window of screening records holds twice the wrappers
-    const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, (latency ? h->latency_top_bytes : h->lds_top_bytes) / window_rec);
+    const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, (latency ? h->latency_top_bytes : (screen && !h->lds_top_set ? h->lds_top_bytes_screen : h->lds_top_bytes)) / window_rec);
     if (top > 0) {   // large scene: the top levels of the tree in LDS, everything else through L2
         a.lds_entries = top;
         size_t bytes = (size_t)top * window_rec;
@@ -1571,7 +1573,7 @@ int32_t cr_create(int32_t device_id, CrHandle** out) {
     if (const char* s = getenv("CRUCIBLE_LATENCY_ENTRIES")) h->latency_entries = (int32_t)std::max(0L, atol(s));
     if (const char* s = getenv("CRUCIBLE_LATENCY_TOP_KB")) h->latency_top_bytes = (size_t)std::max(0L, atol(s)) * 1024;
     if (const char* s = getenv("CRUCIBLE_LDS_SIDE_KB")) h->lds_side_limit = (size_t)std::max(0L, atol(s)) * 1024;
-    if (const char* s = getenv("CRUCIBLE_LDS_TOP_KB")) h->lds_top_bytes = (size_t)std::max(0L, atol(s)) * 1024;
+    if (const char* s = getenv("CRUCIBLE_LDS_TOP_KB")) { h->lds_top_bytes = (size_t)std::max(0L, atol(s)) * 1024; h->lds_top_set = true; }
     if (const char* s = getenv("CRUCIBLE_BLOCKS_PER_CU")) h->blocks_per_cu_override = atoi(s);
     if (const char* s = getenv("CRUCIBLE_BLOCK")) h->block_override = atoi(s);
     if (const char* s = getenv("CRUCIBLE_WALK_ROUND")) h->walk_round_steps = std::max(0, atoi(s));

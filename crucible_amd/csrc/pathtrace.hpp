@@ -1142,6 +1142,15 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
         // the one-or-two-record loop alone; A.leaf_runs is null unless such an element exists (a scalar test)
         if (!ANIM || A.leaf_runs == nullptr || !(leaf & kLeafRun)) {
             const int32_t first = leaf >> 1, count = (leaf & 1) + 1;
+            if constexpr (RES != RES_LDS && !ANIM) {
+                // primitives in global memory: touch the second record's lines while the first is being tested, so that its own
+                // loads hit L1 instead of waiting a second L2 round trip (teapot +1.5 %, 1M spheres +1.4 %)
+                GlobPtr<uint32_t> nx = (GlobPtr<uint32_t>)(const void*)(prims + first + (count - 1));
+                const uint32_t t0 = nx[0], t1 = nx[20];
+                test(first);
+                asm volatile("" :: "v"(t0), "v"(t1));
+                if (count == 2) test(first + 1);
+            } else
             for (int32_t k = 0; k < count; k++) test(first + k);
         } else {
             const int32_t first = A.leaf_runs[2 * (leaf & kLeafRunIndex)], count = A.leaf_runs[2 * (leaf & kLeafRunIndex) + 1];
