@@ -144,6 +144,8 @@ struct CrHandle {
     // an earlier exit.  CRUCIBLE_WALK_ROUND / CRUCIBLE_WALK_EXIT override.
     int walk_round_steps = -1;         // wrappers a lane may step through per round; 0 = until every walking lane found a leaf or ran out
     int walk_exit_lanes = -1;          // leave the walk phase once this many lanes are not walking (64 = wait for all)
+    int walk_leaf_min = -1;            // CRUCIBLE_WALK_LEAF_MIN: parked lanes a leaf phase waits for while others can still step (0 = every round; default 8:
+                                       // book1 +1.5 %, movie frame +1.5 %, 1M spheres +2.9 %, profiles/experiments/r03_leaf_min.txt)
     int last_block = 0, last_grid = 0;
     bool check_abort = false;          // the last launch was a queue kernel whose abort word has not been read yet
 };
@@ -1375,6 +1377,7 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     a.out = (real*)d_out;
     a.walk_exit_lanes = (uint32_t)(h->walk_exit_lanes >= 0 ? h->walk_exit_lanes : (ds.has_triangles ? 40 : 56));
     a.walk_round_steps = (uint32_t)(h->walk_round_steps >= 0 ? h->walk_round_steps : (ds.has_triangles ? 8 : 10));
+    a.walk_leaf_min = h->pipeline == 0 ? (uint32_t)(h->walk_leaf_min >= 0 ? h->walk_leaf_min : 8) : 0u;   // the other pipelines test a leaf in the round that found it
     a.sg_on = 0; a.sg_lw = a.sg_lh = 3; a.sg_groups = 0; a.sg_total = 0; a.sample_buf = nullptr;   // set by launch()
 
     // the ANIM kernels also carry the decode of leaves that hold a HitList element (pathtrace.hpp walk_round)
@@ -1578,6 +1581,7 @@ int32_t cr_create(int32_t device_id, CrHandle** out) {
     if (const char* s = getenv("CRUCIBLE_BLOCK")) h->block_override = atoi(s);
     if (const char* s = getenv("CRUCIBLE_WALK_ROUND")) h->walk_round_steps = std::max(0, atoi(s));
     if (const char* s = getenv("CRUCIBLE_WALK_EXIT")) h->walk_exit_lanes = std::min(64, std::max(1, atoi(s)));
+    if (const char* s = getenv("CRUCIBLE_WALK_LEAF_MIN")) h->walk_leaf_min = std::min(64, std::max(0, atoi(s)));
     if (const char* s = getenv("CRUCIBLE_PIPELINE")) h->pipeline = strcmp(s, "mega") == 0 ? 0 : (strcmp(s, "queue") == 0 ? 2 : 1);
     if (const char* s = getenv("CRUCIBLE_QUEUE_BATCH")) h->queue_min_batch = std::min(64, std::max(1, atoi(s)));
     if (const char* s = getenv("CRUCIBLE_QUEUE_PATIENCE")) h->queue_patience = std::max(0, atoi(s));

@@ -267,6 +267,7 @@ template <typename real> struct KernelArgs {
     real* out;
     uint32_t walk_exit_lanes;   // megakernel: leave the walk once this many lanes are done walking (speed only)
     uint32_t walk_round_steps;  // wrappers a lane may step through before the wave intersects the parked leaves (speed only)
+    uint32_t walk_leaf_min;     // parked lanes a leaf phase waits for while other lanes can still step (speed only; 0 = every round)
     uint32_t queue_walk_waves;  // queue_kernel: how many of the workgroup's 16 waves walk (the rest shade)
     uint32_t queue_min_batch, queue_patience;   // queue_kernel: shaders wait for this many hits, at most this many polls
     // CR_SUM_RELAXED (the RELAX kernels): per-pixel fixed-point sums instead of per-sample colours.  A finished sample adds
@@ -986,6 +987,7 @@ template <typename real> struct WalkState {
     int32_t idx;         // next wrapper to visit; n_entries = walk finished
     bool exact_box;      // an infinite 1/dir component: Aabb::hit's compare/select form is required
     int32_t oct;         // ordered walk: bit a set when direction[a] < 0
+    int32_t pending;     // a leaf wrapper whose box was hit and whose primitives are still to be tested (-1: none)
 };
 
 template <typename real> CR_D void walk_begin(WalkState<real>& w, V3<real> rd) {
@@ -994,7 +996,7 @@ template <typename real> CR_D void walk_begin(WalkState<real>& w, V3<real> rd) {
     // compare/select form reproduces Aabb::hit
     w.exact_box = (r_abs(w.inv.x) == r_inf(real(0))) || (r_abs(w.inv.y) == r_inf(real(0))) || (r_abs(w.inv.z) == r_inf(real(0)));
     w.dd = len2(rd);
-    w.idx = 0; w.best_t = r_inf(real(0)); w.best = -1;
+    w.idx = 0; w.best_t = r_inf(real(0)); w.best = -1; w.pending = -1;
     w.oct = (rd.x < real(0) ? 1 : 0) | (rd.y < real(0) ? 2 : 0) | (rd.z < real(0) ? 4 : 0);
 }
 
@@ -1033,8 +1035,8 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
     // SCREEN kernels keep only screening records in LDS: the rare f64 record is read from global memory
     constexpr int RES64 = SCREEN ? RES_GLOBAL : RES;
     const int32_t lds_n64 = SCREEN ? 0 : A.lds_entries;
-    int32_t leaf = -1;
-    if (walking) {
+    int32_t leaf = w.pending;
+    if (walking && leaf < 0) {
         CR_DIAG_HIT(dg, DG_ROUND_WAVE, DG_ROUND_LANE);
         // SCREEN kernels: steps the f32 loop could not take -- one, for a lane it left at a box too close to call, or all of
         // them for a ray outside its range -- are made below with Aabb::hit's own compare/select form on the f64 records
@@ -1115,6 +1117,16 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
             if (hit && e.leaf >= 0) { leaf = e.leaf; break; }
         }
     }
+    // The parked lanes intersect their leaves together; with walk_leaf_min set, a thin group waits (parked) while other lanes
+    // of the wave can still step, so that the expensive primitive test runs with more lanes.  Per lane the sequence of
+    // operations is unchanged: a parked lane does nothing until its leaf is tested.
+    w.pending = leaf;
+    if (A.walk_leaf_min > 0u) {
+        const uint32_t parked = (uint32_t)__popcll(__ballot(leaf >= 0));
+        const bool can_step = __ballot(walking && leaf < 0 && w.idx < n_entries) != 0ull;
+        if (parked < A.walk_leaf_min && can_step) return;
+    }
+    w.pending = -1;
     if (leaf >= 0) {
         CR_DIAG_HIT(dg, DG_LEAFPH_WAVE, DG_LEAFPH_LANE);
         auto test = [&](int32_t pi) {
@@ -1286,7 +1298,7 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
     unsigned long long c_node = 0;
     // walk state, kept across rounds: a lane whose walk is cut short resumes where it stopped
     WalkState<real> ws;
-    ws.inv = mk<real>(0, 0, 0); ws.dd = 0; ws.best_t = 0; ws.best = -1; ws.idx = 0; ws.exact_box = false;
+    ws.inv = mk<real>(0, 0, 0); ws.dd = 0; ws.best_t = 0; ws.best = -1; ws.idx = 0; ws.exact_box = false; ws.pending = -1;
     const int32_t n_entries = A.n_entries;
 
     Diag* dgp = nullptr;
@@ -1391,7 +1403,7 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
         if (__ballot(state == ST_WALK)) {
             for (;;) {
                 walk_round<real, RES, ANIM, ORD, SCREEN>(A, lds_entries, prims, ro, rd, rtime, ws, state == ST_WALK, A.walk_round_steps, c_node, c_prim, dgp, lds_screen);
-                if (state == ST_WALK && ws.idx >= n_entries) state = ST_SHADE;
+                if (state == ST_WALK && ws.idx >= n_entries && ws.pending < 0) state = ST_SHADE;
                 const uint64_t walking = __ballot(state == ST_WALK);
                 if (!walking || 64u - (uint32_t)__popcll(walking) >= A.walk_exit_lanes) break;
             }

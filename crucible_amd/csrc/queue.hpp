@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(1024) queue_kernel(const KernelArgs<real> A) {
         V3<real> ro = mk<real>(0, 0, 0), rd = mk<real>(0, 0, 1);
         real rtime = 0;
         WalkState<real> ws;
-        ws.inv = mk<real>(0, 0, 0); ws.dd = 0; ws.best_t = 0; ws.best = -1; ws.idx = 0; ws.exact_box = false;
+        ws.inv = mk<real>(0, 0, 0); ws.dd = 0; ws.best_t = 0; ws.best = -1; ws.idx = 0; ws.exact_box = false; ws.pending = -1;
         for (;;) {
             const uint64_t need = __ballot(!has_ray);
             if (need) {

@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(MaxBlock<real>::value) wf_extend_kernel(const 
     V3<real> ro = mk<real>(0, 0, 0), rd = mk<real>(0, 0, 1);
     real rtime = 0;
     WalkState<real> ws;
-    ws.inv = mk<real>(0, 0, 0); ws.dd = 0; ws.best_t = 0; ws.best = -1; ws.idx = 0; ws.exact_box = false;
+    ws.inv = mk<real>(0, 0, 0); ws.dd = 0; ws.best_t = 0; ws.best = -1; ws.idx = 0; ws.exact_box = false; ws.pending = -1;
     uint32_t c_prim = 0;
     unsigned long long c_node = 0;
 
