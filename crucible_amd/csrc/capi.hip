@@ -130,12 +130,13 @@ struct CrHandle {
     int sg_lw = -1, sg_lh = -1;          // CRUCIBLE_SG_TILE=WxH (powers of two, W*H <= 64); default 4x4 pixels x 4 samples
     // f32 trees with more than latency_entries wrappers run on pathtrace_kernel_latency (6 waves/SIMD) with a
     // latency_top_bytes LDS window, three 512-thread groups per CU.  CRUCIBLE_LATENCY_ENTRIES (0 = never).
-    int32_t latency_entries = 65536;
+    int32_t latency_entries = 0;         // (round 3: never by default -- with relaxed sums, the early touch of the leaf's second primitive and the deferred
+                                         //  leaf phases the regular kernel is 6.7 % faster on the 1M-sphere tree: 1770 against 1658 Msamples/s)
     size_t latency_top_bytes = 48 * 1024;
     size_t lds_side_limit = 16 * 1024;   // RES_TOP: materials + textures join the LDS window up to this size (CRUCIBLE_LDS_SIDE_KB; 0 = never)
-    size_t lds_top_bytes = 64 * 1024;   // LDS spent on the top of a tree that does not fit whole (CRUCIBLE_LDS_TOP_KB; 0 = none)
-    size_t lds_top_bytes_screen = 128 * 1024;   // ... by the f64 SCREEN kernels (4096 screening records: one workgroup per CU has the LDS to itself; teapot +2.5 %)
-    bool lds_top_set = false;           // CRUCIBLE_LDS_TOP_KB given: it applies to every kernel
+    size_t lds_top_bytes = 128 * 1024;  // LDS spent on the top of a tree that does not fit whole (CRUCIBLE_LDS_TOP_KB; 0 = none): 4096 32-byte records
+                                        // (f32 wrappers, or the f64 kernels' screening records) -- one 1024-thread workgroup per CU has the LDS to itself; teapot +2.5 %
+    bool lds_top_set = false;           // CRUCIBLE_LDS_TOP_KB given
     int blocks_per_cu_override = 0;
     int block_override = 0;
     // Wave scheduling of the walk (speed only).  -1 = chosen per scene: sphere scenes 10 / 56, scenes with triangles 8 / 40 --
@@ -1401,7 +1402,7 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
         }
         const bool latency = f32 && h->latency_entries > 0 && ds.n_entries > h->latency_entries;
         const size_t window_rec = screen ? sizeof(ScreenEntryO) : sizeof(EntryO<real>);
-        const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, (latency ? h->latency_top_bytes : (screen && !h->lds_top_set ? h->lds_top_bytes_screen : h->lds_top_bytes)) / window_rec);
+        const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, (latency ? h->latency_top_bytes : h->lds_top_bytes) / window_rec);
         if (top > 0) {
             a.lds_entries = top;
             const size_t bytes = (size_t)top * window_rec;
@@ -1436,7 +1437,7 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     constexpr bool f32 = std::is_same<real, float>::value;   // the double kernel needs far more than 80 VGPRs: it halves there
     const bool latency = f32 && h->latency_entries > 0 && ds.n_entries > h->latency_entries;
     const size_t window_rec = screen ? sizeof(ScreenEntry) : sizeof(Entry<real>);   // a window of screening records holds twice the wrappers
-    const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, (latency ? h->latency_top_bytes : (screen && !h->lds_top_set ? h->lds_top_bytes_screen : h->lds_top_bytes)) / window_rec);
+    const int32_t top = (int32_t)std::min<size_t>((size_t)ds.n_entries, (latency ? h->latency_top_bytes : h->lds_top_bytes) / window_rec);
     if (top > 0) {   // large scene: the top levels of the tree in LDS, everything else through L2
         a.lds_entries = top;
         size_t bytes = (size_t)top * window_rec;

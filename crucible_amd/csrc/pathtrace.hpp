@@ -1515,8 +1515,8 @@ template <typename real> CR_D const KernelArgs<real>& kernel_args() {
 }
 template <typename real, int RES, bool ANIM, bool ORD = false, bool CAMK = false, bool RELAX = false, bool SCREEN = false>
 __global__ void __launch_bounds__(MaxBlock<real>::value) pathtrace_kernel(const KernelArgs<real> A) {
-    // f32 kernels have registers to spare and lose 1 % to the reloads: they keep the by-value parameter
-    if constexpr (std::is_same<real, double>::value) pathtrace_body<real, RES, ANIM, ORD, CAMK, RELAX, SCREEN>(kernel_args<real>());
+    // the LDS-resident f32 kernels have registers to spare and lose 1 % to the reloads: they keep the by-value parameter
+    if constexpr (std::is_same<real, double>::value || RES != RES_LDS) pathtrace_body<real, RES, ANIM, ORD, CAMK, RELAX, SCREEN>(kernel_args<real>());
     else pathtrace_body<real, RES, ANIM, ORD, CAMK, RELAX, SCREEN>(A);
 }
 
