@@ -127,6 +127,8 @@ struct CrHandle {
     int sample_granular = 1;             // CRUCIBLE_SAMPLE_GRANULAR=0: a lane owns a pixel (no buffer)
     size_t sample_buf_limit = (size_t)40 << 30;   // CRUCIBLE_SAMPLE_BUF_MB (MI355X: 288 GB of HBM)
     int sg_chunk_override = 0;           // CRUCIBLE_SG_CHUNK: items per atomic (default: by launch size)
+    uint64_t work_counter_max = 0xF0000000ull;   // work items one launch may hand out (32-bit counter); more samples run as consecutive launches
+                                         // (CRUCIBLE_WORK_COUNTER_MAX: tests shrink it to reach that path on small frames)
     int sg_lw = -1, sg_lh = -1;          // CRUCIBLE_SG_TILE=WxH (powers of two, W*H <= 64); default 4x4 pixels x 4 samples
     // f32 trees with more than latency_entries wrappers run on pathtrace_kernel_latency (6 waves/SIMD) with a
     // latency_top_bytes LDS window, three 512-thread groups per CU.  CRUCIBLE_LATENCY_ENTRIES (0 = never).
@@ -941,7 +943,7 @@ int32_t launch(CrHandle* h, const KernelArgs<real>& args_in, size_t scene_lds_by
         args.tiles_y = ((uint32_t)args.cam.H + (1u << lh) - 1) >> lh;
         const uint64_t tiles = (uint64_t)args.tiles_x * args.tiles_y;
         // the 32-bit work counter must hold tiles * groups * 64 plus one chunk per wave
-        const uint64_t max_groups = 0xF0000000ull / (tiles * 64);
+        const uint64_t max_groups = h->work_counter_max / (tiles * 64);
         if (max_groups < 1) batch = 0;
         else batch = (int32_t)std::min<uint64_t>((uint64_t)batch, max_groups * ns);
         // the buffer holds one colour per work item of a batch: whole tiles and whole sample groups (edge padding included)
@@ -1568,6 +1570,7 @@ int32_t cr_create(int32_t device_id, CrHandle** out) {
     if (const char* s = getenv("CRUCIBLE_SUM_ORDER")) h->default_sum_order = strcmp(s, "reference") == 0 ? CR_SUM_REFERENCE_ORDER : CR_SUM_RELAXED;
     if (const char* s = getenv("CRUCIBLE_SAMPLE_BUF_MB")) h->sample_buf_limit = (size_t)std::max(0L, atol(s)) << 20;
     if (const char* s = getenv("CRUCIBLE_SG_CHUNK")) h->sg_chunk_override = std::max(0, atoi(s));
+    if (const char* s = getenv("CRUCIBLE_WORK_COUNTER_MAX")) h->work_counter_max = std::min<uint64_t>(0xF0000000ull, (uint64_t)std::max(64LL, atoll(s)));
     if (const char* s = getenv("CRUCIBLE_SG_TILE")) {
         int tw = 0, th = 0;
         if (sscanf(s, "%dx%d", &tw, &th) == 2 && tw > 0 && th > 0 && (tw & (tw - 1)) == 0 && (th & (th - 1)) == 0 && tw * th <= 64) {

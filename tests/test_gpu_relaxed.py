@@ -145,6 +145,28 @@ def test_relaxed_frame_does_not_depend_on_scheduling(renderer, monkeypatch, env)
         r.close()
 
 
+@pytest.mark.parametrize("limit", ["50000", "23000"], ids=["8-sample-launches", "4-sample-launches"])
+def test_relaxed_sums_survive_several_launches(renderer, monkeypatch, limit):
+    """A frame with more work items than one launch's 32-bit counter may hand out (a 4K frame beyond ~480 spp) runs as consecutive
+    launches that keep adding to the same per-pixel sums.  CRUCIBLE_WORK_COUNTER_MAX shrinks the counter's range so that a 100 x 56
+    frame at 21 spp needs three to six launches: the frame and the counters must be those of the one-launch render, bit for bit --
+    also in the parity mode, whose batches it cuts the same way."""
+    sc = book1_end_scene(1, scene_seed=1, image_width=100, samples=21)
+    want = {}
+    for rt, _ in REALS:
+        want[rt] = (relaxed(renderer, sc, rt), (renderer.render(sc.scene_cam, seed=SEED, real_type=rt, sum_order=A.CR_SUM_REFERENCE_ORDER)))
+    monkeypatch.setenv("CRUCIBLE_WORK_COUNTER_MAX", limit)
+    r = Renderer(0)
+    try:
+        r.upload_scene(sc.flatten())
+        for rt, _ in REALS:
+            for k, order in enumerate((RELAX, A.CR_SUM_REFERENCE_ORDER)):
+                img, st = r.render(sc.scene_cam, seed=SEED, real_type=rt, sum_order=order)
+                assert np.array_equal(img, want[rt][k][0]) and all(st[c] == want[rt][k][1][c] for c in COUNTERS), (rt, order)
+    finally:
+        r.close()
+
+
 def test_relaxed_is_the_library_default(monkeypatch, o64):
     """CR_SUM_DEFAULT resolves to the relaxed sums unless CRUCIBLE_SUM_ORDER=reference (which the test session sets for
     the bit-exact tests); the alternative pipelines are reference-order only."""
