@@ -60,6 +60,7 @@ template <typename real> struct DevScene {
     size_t lds_bytes = 0;
     bool animated = false;
     bool has_triangles = false;
+    bool has_spheres = false;
     bool has_leaf_runs = false;              // some leaf names its primitives through leaf_runs (a HitList element)
     bool has_bvh_elements = false;           // CR_BVH_REFERENCE over a BVHWrapper element: the records are not the reference's wrappers one to one (no export)
     bool has_lists = false;                  // the tree was built over at least one HitList element: its construction-time box
@@ -572,7 +573,7 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
     b.order.resize(n);
     std::vector<Prim<real>> src(n);
     bool any_keys = false, any_lists = false;
-    ds.has_triangles = false;
+    ds.has_triangles = false; ds.has_spheres = false;
     auto make_prim = [&](const CrPrimitive& p) {
         Prim<real> q;
         memset(&q, 0, sizeof q);
@@ -582,6 +583,7 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
         q.key_first = p.key_first; q.key_count = p.key_count;
         any_keys |= p.key_count > 0;
         ds.has_triangles |= p.kind == CR_PRIM_TRIANGLE;
+        ds.has_spheres |= p.kind == CR_PRIM_SPHERE;
         return q;
     };
     auto prim_box = [](const Prim<real>& q, real lo[3], real hi[3]) {
@@ -1378,6 +1380,7 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     a.work_counter = (uint32_t*)h->work_counter.p;
     a.counters = (uint64_t*)h->counters.p;
     a.out = (real*)d_out;
+    a.uniform_kind = (ds.has_spheres && !ds.has_triangles) ? 0 : ((ds.has_triangles && !ds.has_spheres) ? 1 : -1);
     a.walk_exit_lanes = (uint32_t)(h->walk_exit_lanes >= 0 ? h->walk_exit_lanes : (ds.has_triangles ? 40 : 56));
     a.walk_round_steps = (uint32_t)(h->walk_round_steps >= 0 ? h->walk_round_steps : (ds.has_triangles ? 8 : 10));
     a.walk_leaf_min = h->pipeline == 0 ? (uint32_t)(h->walk_leaf_min >= 0 ? h->walk_leaf_min : 8) : 0u;   // the other pipelines test a leaf in the round that found it

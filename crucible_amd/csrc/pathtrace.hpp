@@ -268,6 +268,7 @@ template <typename real> struct KernelArgs {
     uint32_t walk_exit_lanes;   // megakernel: leave the walk once this many lanes are done walking (speed only)
     uint32_t walk_round_steps;  // wrappers a lane may step through before the wave intersects the parked leaves (speed only)
     uint32_t walk_leaf_min;     // parked lanes a leaf phase waits for while other lanes can still step (speed only; 0 = every round)
+    int32_t uniform_kind;       // 0 / 1: every primitive is a sphere / a triangle (the test need not load the record's kind word); -1: mixed
     uint32_t queue_walk_waves;  // queue_kernel: how many of the workgroup's 16 waves walk (the rest shade)
     uint32_t queue_min_batch, queue_patience;   // queue_kernel: shaders wait for this many hits, at most this many polls
     // CR_SUM_RELAXED (the RELAX kernels): per-pixel fixed-point sums instead of per-sample colours.  A finished sample adds
@@ -1136,7 +1137,8 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
             real t;
             bool h;
             real g0 = p.g[0], g1 = p.g[1], g2 = p.g[2], g3 = p.g[3];
-            if (p.kind() == 0) {
+            const int32_t kind = A.uniform_kind >= 0 ? A.uniform_kind : p.kind();   // a scalar test; one load fewer per primitive when it holds
+            if (kind == 0) {
                 if (ANIM && p.key_count) timeline_eval(A.keys + p.key_first, p.key_count, rtime, g0, g1, g2, g3);
                 h = sphere_t(g0, g1, g2, g3, ro, rd, w.dd, tmin, w.best_t, t);
             } else {
