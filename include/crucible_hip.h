@@ -265,9 +265,12 @@ typedef struct CrCameraDesc {
  *                           round(colour * 2^52) in a 64-bit integer (2^51, 2^50, ... beyond 2047 samples per pixel).
  *                           Integer adds commute, so the frame is deterministic -- two runs, or any split into
  *                           shards, give the same sums.  Per channel the mean differs from the reference order by
- *                           at most (max_depth + 2) * 2^-53 relative per sample, i.e. below 1e-14 at depth 50 (tested:
- *                           <= 1e-12 against the oracle, equal counters, equal PPM bytes).  No per-sample buffer and no
- *                           stack: 24 bytes of device memory per pixel.
+ *                           at most about (2 * max_depth + samples) * 2^-53: each of the two product orders rounds
+ *                           max_depth times, and the reference's own sequential sum rounds once per sample where the
+ *                           integer sum does not -- below 1e-13 at depth 50 and 512 samples, 1.0e-14 measured on the
+ *                           headline frame (tested: <= 1e-12 against the oracle, equal counters, equal PPM bytes up to
+ *                           values that sit on a byte boundary).  No per-sample buffer and no stack: 24 bytes of device
+ *                           memory per pixel.
  *   CR_SUM_DEFAULT          the library's choice: CR_SUM_RELAXED (see DESIGN.md section 3.3 for the measurement);
  *                           the environment variable CRUCIBLE_SUM_ORDER=reference|relaxed overrides it.
  */
