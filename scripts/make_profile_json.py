@@ -39,7 +39,7 @@ lane = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
 wc = c["SQ_WAVE_CYCLES"]
 issuing, waiting = c["SQ_ACTIVE_INST_ANY"] / wc, c["SQ_WAIT_ANY"] / wc
 rec = {
-    "kernel": meta.get("_kernel"), "workgroup_size": meta.get("_Workgroup_Size"), "arch_vgprs": meta.get("_VGPR_Count"),
+    "kernel": meta.get("_kernel"), "workgroup_size": meta.get("_Workgroup_Size"), "rocprof_arch_vgpr_count": meta.get("_VGPR_Count"), "rocprof_arch_vgpr_count_note": "rocprofv3 reports HALF the allocation on gfx950; the allocation is in profiles/r03_kernel_resources.json",
     "shader_cycles": round(cycles), "valu_instr_per_simd_cycle": round(valu, 4), "guide_peak_instr_per_simd_cycle": 0.5,
     "issue_busy_vs_guide_peak": round(valu / 0.5, 4), "lane_utilisation": round(lane, 4),
     "valu_lane_roofline_frac": round(valu / 0.5 * lane, 4),
