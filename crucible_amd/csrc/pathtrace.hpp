@@ -1185,14 +1185,14 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
 enum : int { ST_NEED_PIXEL = 0, ST_NEED_SAMPLE = 1, ST_TRACE = 2, ST_DONE = 3, ST_WALK = 4, ST_SHADE = 5 };
 
 // Largest workgroup the kernels may be launched with.  The launch bound caps the register allocation:
-// 1024 threads = 4 waves/SIMD = 128 VGPRs.  The f32 kernel needs ~95; the f64 kernel would like ~185 and
-// spills ~46 registers to scratch under this cap, yet 4 waves/SIMD with those spills measured 7 % faster
-// than 2 waves/SIMD without (1955 vs 1830 Msamples/s on book1).
+// 1024 threads = 4 waves/SIMD = 128 VGPRs.  The f32 kernels need ~103; the f64 kernels sit at the cap with 10-18 VGPRs
+// spilled to scratch (profiles/r03_kernel_resources.json) -- in round 1 the f64 kernel at 4 waves/SIMD with its spills
+// measured 7 % faster than at 2 waves/SIMD without, and 5 waves/SIMD (<= 96 VGPRs, 78 spills) loses 32 %.
 template <typename real> struct MaxBlock { static constexpr int value = 1024; };
 
-// One lane = one pixel at a time, all of that pixel's samples in draw order (so the
-// per-pixel sum is the reference's sequential sum).  Lanes that finish a pixel pull the
-// next pixel index with one wave-aggregated atomic (ballot + prefix count).
+// The persistent kernel body.  A work item is one (pixel, sample) handed out in chunks from one global counter (sample-granular
+// mode, the default); the reference-order variants keep per-sample colours for the ordered sum, the RELAX variants add into
+// fixed-point per-pixel sums.  (sg_on = 0, a fallback: one lane owns a pixel and sums its samples in draw order itself.)
 // RELAX: CR_SUM_RELAXED -- the same paths (same draws, same walks, same counters); a finished sample's colour is
 // thr * sky and goes into fixed-point per-pixel sums.  Each wave owns two LDS accumulators, one work tile (<= 16
 // pixels x 3 channels) each: ds_add_u64 there, and one global atomic per word when the wave moves on to another tile
