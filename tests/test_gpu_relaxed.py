@@ -23,6 +23,14 @@ TOL = {A.CR_REAL_F64: 1e-12,   # bound: about (2 * 50 + samples) * 2^-53 < 1e-13
        A.CR_REAL_F32: 4e-6}    # the f32 oracle adds its samples sequentially in f32 (n * 2^-24 per channel); relaxed f32 adds exactly
 
 
+def _movie_frame(frame):
+    """One frame of configs[4] (the teapot orbit: keyed camera, the CAMK kernels) at full width, 3 spp."""
+    from crucible_amd.demo_builder import teapot_orbit_movie
+    sc = teapot_orbit_movie(1, image_width=1920, samples=3)
+    sc.scene_cam.frame = frame
+    return sc
+
+
 def relaxed(renderer, sc, rt, **kw):
     renderer.upload_scene(sc.flatten())
     return renderer.render(sc.scene_cam, seed=kw.pop("seed", SEED), real_type=rt, sum_order=RELAX, **kw)
@@ -241,6 +249,7 @@ def test_relaxed_with_the_opt_in_trees(renderer, rt, tag, bvh):
     ("C2-book1-1080p", lambda: book1_end_scene(1, scene_seed=1, image_width=1920, samples=8), (0, 540, 1079)),
     ("C3-teapot-1080p", lambda: load_teapot(1, image_width=1920, samples=4, sky=procedural_sky()), (300, 700)),
     ("C4-million-4k", lambda: million_spheres(1, scene_seed=1, image_width=3840, samples=2), (1200,)),
+    ("C5-movie-frame-1080p", lambda: _movie_frame(97), (450,)),
 ])
 def test_relaxed_full_size_frames(renderer, o64, name, build, rows):
     """The BASELINE frames at full size: equal counters and equal PPM bytes against the GPU's reference-order render of the
