@@ -22,10 +22,11 @@ static void dump_desc(const FlatScene& f, const char* path) {
     if (!fp) { perror("dump"); exit(2); }
     int32_t hdr[7] = {f.desc.n_prims, f.desc.n_materials, f.desc.n_textures, f.desc.n_images, f.desc.n_keys, f.desc.sky_kind, f.desc.sky_image};
     fwrite(hdr, sizeof hdr, 1, fp);
-    fwrite(f.prims.data(), sizeof(CrPrimitive), f.prims.size(), fp);
-    fwrite(f.materials.data(), sizeof(CrMaterial), f.materials.size(), fp);
-    fwrite(f.textures.data(), sizeof(CrTexture), f.textures.size(), fp);
-    fwrite(f.keys.data(), sizeof(CrKeyframe), f.keys.size(), fp);
+    auto put = [fp](const void* p, size_t size, size_t n) { if (n) fwrite(p, size, n, fp); };   // an empty vector's data() may be null
+    put(f.prims.data(), sizeof(CrPrimitive), f.prims.size());
+    put(f.materials.data(), sizeof(CrMaterial), f.materials.size());
+    put(f.textures.data(), sizeof(CrTexture), f.textures.size());
+    put(f.keys.data(), sizeof(CrKeyframe), f.keys.size());
     for (const CrImage& im : f.images) {
         int32_t wh[2] = {im.width, im.height};
         fwrite(wh, sizeof wh, 1, fp);
