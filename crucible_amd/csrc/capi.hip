@@ -1362,7 +1362,7 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     // per step), see walk_round (A/B in profiles/experiments/r03_screen_ab.txt).
     bool screen = false;
     if constexpr (std::is_same<real, double>::value) {
-        screen = h->pipeline == 0 && ds.screen.p != nullptr && ds.n_entries > 0 && h->screen_boxes;
+        screen = h->pipeline == 0 && ds.screen.p != nullptr && ds.n_entries > 0 && h->screen_boxes && (ds.ordered || ds.n_entries < kScreenMaxEntries);
         if (screen) {
             a.screen = ds.screen.p;
             if (refit) {

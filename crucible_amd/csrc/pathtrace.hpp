@@ -169,11 +169,17 @@ template <typename real> struct EntryOf<real, true> { using type = EntryO<real>;
 // f64 kernels: the f32 SCREENING copy of a wrapper -- the box rounded to f32, the same links.  The walk decides most box
 // tests on this 32-byte record (half the bytes of Entry<double>) and reads the f64 box only when the f32 result is too
 // close to call (screen_step below; DESIGN.md section 3.4 has the error bound).
+// The links are stored the way the walk's inner loop consumes them: `skip` = BYTE offset of the wrapper to visit after a
+// miss (index * 32; n_entries * 32 ends the walk) and `hit` = what a box hit leads to -- the byte offset of the left child, or
+// kScreenLeaf | leaf code for a leaf wrapper.  One select picks the next offset and ONE unsigned compare (next >= n_entries * 32)
+// sees both ways out of the loop; the offset is the LDS address / the 32-bit offset of a global load as it stands.
 struct alignas(16) ScreenEntry {
     float b[6];
-    int32_t skip;
-    int32_t leaf;
+    uint32_t skip;
+    uint32_t hit;
 };
+constexpr uint32_t kScreenLeaf = 0x80000000u;
+constexpr int32_t kScreenMaxEntries = 1 << 26;   // offsets stay below bit 31
 // ... and of an EntryO (CR_BVH_SAH_ORDERED): 64 bytes instead of 96.
 struct alignas(16) ScreenEntryO {
     float b[6];
@@ -942,29 +948,32 @@ CR_D Entry<real> fetch_entry_ordered(const Entry<real>* lds, const Entry<real>* 
     return rd((const EntryO<real>*)glob);
 }
 
-// A screening record, from the LDS copy or from global memory (RES_TOP: the LDS window holds the first lds_n of them).
+// A screening record by its byte offset, from the LDS copy or from global memory (RES_TOP: the LDS window holds the first
+// lds_bytes of the array).
 template <int RES>
-CR_D ScreenEntry fetch_screen(const ScreenEntry* lds, const ScreenEntry* glob, int32_t lds_n, int32_t idx) {
-    if (RES == RES_LDS) return lds[idx];
+CR_D ScreenEntry fetch_screen(const ScreenEntry* lds, const ScreenEntry* glob, uint32_t lds_bytes, uint32_t off) {
+    static_assert(sizeof(ScreenEntry) == 32, "offsets are index << 5");
+    if (RES == RES_LDS) return *(const ScreenEntry*)((const char*)lds + off);
     if (RES == RES_TOP) {
         ScreenEntry e;
         uint32_t* o = reinterpret_cast<uint32_t*>(&e);
-        if (idx < lds_n) {
-            LdsPtr<uint32_t> s = (LdsPtr<uint32_t>)(const void*)(lds + idx);
+        if (off < lds_bytes) {
+            LdsPtr<uint32_t> s = (LdsPtr<uint32_t>)(const void*)((const char*)lds + off);
             for (int k = 0; k < 8; k++) o[k] = s[k];
         } else {
-            GlobPtr<uint32_t> s = (GlobPtr<uint32_t>)(const void*)(glob + idx);
+            GlobPtr<uint32_t> s = (GlobPtr<uint32_t>)(const void*)((const char*)glob + off);
             for (int k = 0; k < 8; k++) o[k] = s[k];
         }
         return e;
     }
-    return glob[idx];
+    return *(const ScreenEntry*)((const char*)glob + off);
 }
 
 // The ordered layout's screening record read into the same shape: skip = the link of the ray's octant.
+struct ScreenStep { float b[6]; int32_t skip; int32_t leaf; };
 template <int RES>
-CR_D ScreenEntry fetch_screen_ordered(const ScreenEntryO* lds, const ScreenEntryO* glob, int32_t lds_n, int32_t idx, int32_t oct) {
-    ScreenEntry e;
+CR_D ScreenStep fetch_screen_ordered(const ScreenEntryO* lds, const ScreenEntryO* glob, int32_t lds_n, int32_t idx, int32_t oct) {
+    ScreenStep e;
     if (RES == RES_LDS || (RES == RES_TOP && idx < lds_n)) {
         const ScreenEntryO* s = lds + idx;
         LdsPtr<float> b = (LdsPtr<float>)s->b;
@@ -1061,13 +1070,11 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
                 const float th0 = __builtin_fmaf(0x1.0p-21f, r_max(r_max(qx, qy), qz), __builtin_fmaf(pmax * 0x1.0p-100f, 0x1.0p-47f, 1e-35f));
                 asm volatile("" : "+v"(tmaxf));   // keep it in a register: the allocator would re-convert tmax at every step
                 uint32_t nodes = 0;
-                // `it` is the same in every lane still in the loop (a scalar register)
-                for (uint32_t it = 0; w.idx < n_entries; it++) {
-                    const ScreenEntry se = ORD ? fetch_screen_ordered<RES>((const ScreenEntryO*)lds_screen, (const ScreenEntryO*)A.screen, A.lds_entries, w.idx, w.oct)
-                                               : fetch_screen<RES>((const ScreenEntry*)lds_screen, (const ScreenEntry*)A.screen, A.lds_entries, w.idx);
-                    const Pair<float> tx = (Pair<float>{se.b[0], se.b[1]} - fox) * fix;
-                    const Pair<float> ty = (Pair<float>{se.b[2], se.b[3]} - foy) * fiy;
-                    const Pair<float> tz = (Pair<float>{se.b[4], se.b[5]} - foz) * fiz;
+                // Aabb::hit of the wrapper at index `idx` decided on its screening box `b`: true = miss
+                auto box_miss = [&](const float* b, int32_t idx) -> bool {
+                    const Pair<float> tx = (Pair<float>{b[0], b[1]} - fox) * fix;
+                    const Pair<float> ty = (Pair<float>{b[2], b[3]} - foy) * fiy;
+                    const Pair<float> tz = (Pair<float>{b[4], b[5]} - foz) * fiz;
                     const float nx = r_min(tx.x, tx.y), ny = r_min(ty.x, ty.y), nz = r_min(tz.x, tz.y);
                     const float fx = r_max(tx.x, tx.y), fy = r_max(ty.x, ty.y), fz = r_max(tz.x, tz.y);
                     const float lo = r_max(r_max(nx, ny), r_max(nz, tminf));
@@ -1079,14 +1086,39 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
                     bool miss = d < 0.0f;
                     if (__builtin_expect(!(__builtin_fabsf(d) > th), 0)) {   // too close to call in f32: Aabb::hit in f64 on the f64 box
                         CR_DIAG_HIT(dg, DG_BAND_WAVE, DG_BAND_LANE);
-                        const Entry<real> e = ORD ? fetch_entry_ordered<real, RES64>(lds_entries, A.entries, lds_n64, w.idx, w.oct)
-                                                  : fetch_entry<real, RES64>(lds_entries, A.entries, lds_n64, w.idx);
+                        const Entry<real> e = ORD ? fetch_entry_ordered<real, RES64>(lds_entries, A.entries, lds_n64, idx, w.oct)
+                                                  : fetch_entry<real, RES64>(lds_entries, A.entries, lds_n64, idx);
                         miss = !box_hit(e.b, ro, w.inv, tmin, w.best_t);
                     }
-                    const bool inner = se.leaf < 0;
-                    w.idx = (inner && !miss) ? (ORD ? ordered_near(se.leaf, w.oct) : -se.leaf) : se.skip;
-                    if (!(miss || inner)) { leaf = se.leaf; break; }
-                    if (it + 1 == budget) break;
+                    return miss;
+                };
+                // `it` is the same in every lane still in the loop (a scalar register)
+                if constexpr (ORD) {
+                    for (uint32_t it = 0; w.idx < n_entries; it++) {
+                        const ScreenStep se = fetch_screen_ordered<RES>((const ScreenEntryO*)lds_screen, (const ScreenEntryO*)A.screen, A.lds_entries, w.idx, w.oct);
+                        const bool miss = box_miss(se.b, w.idx);
+                        const bool inner = se.leaf < 0;
+                        w.idx = (inner && !miss) ? ordered_near(se.leaf, w.oct) : se.skip;
+                        if (!(miss || inner)) { leaf = se.leaf; break; }
+                        if (it + 1 == budget) break;
+                    }
+                } else {
+                    // the lane's position as a byte offset into the record array (ScreenEntry): a lane leaves the loop at the
+                    // end of the array or with a leaf in hand, and one compare sees both
+                    const uint32_t end = (uint32_t)n_entries << 5;
+                    uint32_t off = (uint32_t)w.idx << 5, after_leaf = 0;
+                    if (off < end) {
+                        for (uint32_t it = 0;; it++) {
+                            const ScreenEntry se = fetch_screen<RES>((const ScreenEntry*)lds_screen, (const ScreenEntry*)A.screen, (uint32_t)A.lds_entries << 5, off);
+                            const bool miss = box_miss(se.b, (int32_t)(off >> 5));
+                            after_leaf = se.skip;
+                            off = miss ? se.skip : se.hit;
+                            if (off >= end) break;
+                            if (it + 1 == budget) break;
+                        }
+                        if (off & kScreenLeaf) { leaf = (int32_t)(off & ~kScreenLeaf); off = after_leaf; }
+                        w.idx = (int32_t)(off >> 5);
+                    }
                 }
                 c_node += nodes;
             }
@@ -1541,7 +1573,8 @@ __global__ void __launch_bounds__(256) screen_from_entries_kernel(const Entry<do
     const Entry<double> v = e[i];
     ScreenEntry o;
     for (int k = 0; k < 6; k++) o.b[k] = (float)v.b[k];
-    o.skip = v.skip; o.leaf = v.leaf;
+    o.skip = (uint32_t)v.skip << 5;
+    o.hit = v.leaf < 0 ? (uint32_t)(-v.leaf) << 5 : (kScreenLeaf | (uint32_t)v.leaf);
     s[i] = o;
 }
 
