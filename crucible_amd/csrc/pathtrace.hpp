@@ -948,12 +948,22 @@ CR_D Entry<real> fetch_entry_ordered(const Entry<real>* lds, const Entry<real>* 
     return rd((const EntryO<real>*)glob);
 }
 
+// A kernel that holds ALL screening records in LDS (RES_LDS) rewrites the links of its copy into LDS addresses while staging
+// it, so that the walk's position is the address of the next ds_read as it stands: the address the copy starts at.
+template <int RES> CR_D uint32_t screen_lds_base(const void* lds) { return RES == RES_LDS ? (uint32_t)(uintptr_t)(LdsPtr<char>)lds : 0u; }
 // A screening record by its byte offset, from the LDS copy or from global memory (RES_TOP: the LDS window holds the first
 // lds_bytes of the array).
 template <int RES>
 CR_D ScreenEntry fetch_screen(const ScreenEntry* lds, const ScreenEntry* glob, uint32_t lds_bytes, uint32_t off) {
     static_assert(sizeof(ScreenEntry) == 32, "offsets are index << 5");
-    if (RES == RES_LDS) return *(const ScreenEntry*)((const char*)lds + off);
+    if (RES == RES_LDS) {   // the staged copy holds LDS addresses (screen_lds_base): `off` is one
+        typedef uint32_t Quad __attribute__((ext_vector_type(4)));   // 16-byte aligned: two ds_read_b128
+        ScreenEntry e;
+        Quad* o = reinterpret_cast<Quad*>(&e);
+        LdsPtr<Quad> s = (LdsPtr<Quad>)(uintptr_t)off;
+        o[0] = s[0]; o[1] = s[1];
+        return e;
+    }
     if (RES == RES_TOP) {
         ScreenEntry e;
         uint32_t* o = reinterpret_cast<uint32_t*>(&e);
@@ -1078,19 +1088,28 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
                     const float nx = r_min(tx.x, tx.y), ny = r_min(ty.x, ty.y), nz = r_min(tz.x, tz.y);
                     const float fx = r_max(tx.x, tx.y), fy = r_max(ty.x, ty.y), fz = r_max(tz.x, tz.y);
                     const float lo = r_max(r_max(nx, ny), r_max(nz, tminf));
-                    const float hi = r_min(r_min(fx, fy), r_min(fz, tmaxf));
-                    const float th = __builtin_fmaf(0x1.0p-20f, r_max(__builtin_fabsf(lo), __builtin_fabsf(hi)), th0);
-                    const float d = hi - lo;
+                    // hi = r_min(r_min(fx, fy), r_min(fz, tmaxf)) and m = r_max(|lo|, |hi|), written out: the compiler re-quiets the
+                    // loop-invariant tmaxf with a v_max_f32 x, x at every step (instruction selection works block by block and
+                    // cannot see that it is a number), and one VALU instruction in this loop is about 1.5 % of the frame
+                    float hi, m;
+                    asm("v_min_f32_e32 %0, %2, %3\n\tv_min3_f32 %0, %4, %5, %0\n\tv_max_f32_e64 %1, |%6|, |%0|"
+                        : "=&v"(hi), "=v"(m) : "v"(fz), "v"(tmaxf), "v"(fx), "v"(fy), "v"(lo));
+                    const float th = __builtin_fmaf(0x1.0p-20f, m, th0);
+                    float d = hi - lo;
                     nodes++;
                     CR_DIAG_HIT(dg, DG_BOX_WAVE, DG_BOX_LANE);
-                    bool miss = d < 0.0f;
-                    if (__builtin_expect(!(__builtin_fabsf(d) > th), 0)) {   // too close to call in f32: Aabb::hit in f64 on the f64 box
-                        CR_DIAG_HIT(dg, DG_BAND_WAVE, DG_BAND_LANE);
-                        const Entry<real> e = ORD ? fetch_entry_ordered<real, RES64>(lds_entries, A.entries, lds_n64, idx, w.oct)
-                                                  : fetch_entry<real, RES64>(lds_entries, A.entries, lds_n64, idx);
-                        miss = !box_hit(e.b, ro, w.inv, tmin, w.best_t);
+                    // too close to call in f32: Aabb::hit in f64 on the f64 box.  (The wave tests "any lane?" with a scalar branch and
+                    // the rare lane overwrites d, so that the common path carries no mask bookkeeping for the merge.)
+                    const bool band = !(__builtin_fabsf(d) > th);
+                    if (__builtin_expect(__ballot(band) != 0ull, 0)) {
+                        if (band) {
+                            CR_DIAG_HIT(dg, DG_BAND_WAVE, DG_BAND_LANE);
+                            const Entry<real> e = ORD ? fetch_entry_ordered<real, RES64>(lds_entries, A.entries, lds_n64, idx, w.oct)
+                                                      : fetch_entry<real, RES64>(lds_entries, A.entries, lds_n64, idx);
+                            d = box_hit(e.b, ro, w.inv, tmin, w.best_t) ? 1.0f : -1.0f;
+                        }
                     }
-                    return miss;
+                    return d < 0.0f;
                 };
                 // `it` is the same in every lane still in the loop (a scalar register)
                 if constexpr (ORD) {
@@ -1105,19 +1124,23 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
                 } else {
                     // the lane's position as a byte offset into the record array (ScreenEntry): a lane leaves the loop at the
                     // end of the array or with a leaf in hand, and one compare sees both
-                    const uint32_t end = (uint32_t)n_entries << 5;
-                    uint32_t off = (uint32_t)w.idx << 5, after_leaf = 0;
+                    const uint32_t base = screen_lds_base<RES>(lds_screen);
+                    const uint32_t end = base + ((uint32_t)n_entries << 5);
+                    uint32_t off = base + ((uint32_t)w.idx << 5), after_leaf = 0;
                     if (off < end) {
                         for (uint32_t it = 0;; it++) {
                             const ScreenEntry se = fetch_screen<RES>((const ScreenEntry*)lds_screen, (const ScreenEntry*)A.screen, (uint32_t)A.lds_entries << 5, off);
-                            const bool miss = box_miss(se.b, (int32_t)(off >> 5));
+                            const bool miss = box_miss(se.b, (int32_t)((off - base) >> 5));
                             after_leaf = se.skip;
                             off = miss ? se.skip : se.hit;
-                            if (off >= end) break;
-                            if (it + 1 == budget) break;
+                            // the round's last step ends it for every lane: a scalar select of the limit (hidden from the optimiser,
+                            // which would turn it back into a second exit mask)
+                            uint32_t limit = (it + 1 == budget) ? 0u : end;
+                            asm("" : "+s"(limit));
+                            if (off >= limit) break;
                         }
                         if (off & kScreenLeaf) { leaf = (int32_t)(off & ~kScreenLeaf); off = after_leaf; }
-                        w.idx = (int32_t)(off >> 5);
+                        w.idx = (int32_t)((off - base) >> 5);
                     }
                 }
                 c_node += nodes;
@@ -1266,6 +1289,15 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
             prims = (const Prim<real>*)(smem + o1);
             mats = (const Mat<real>*)(smem + o2);
             texs = (const Tex<real>*)(smem + o3);
+            if constexpr (SCREEN && !ORD) {   // links of the staged screening records become LDS addresses (fetch_screen)
+                __syncthreads();
+                const uint32_t base = screen_lds_base<RES>(smem);
+                ScreenEntry* rec = (ScreenEntry*)smem;
+                for (int32_t i = (int32_t)threadIdx.x; i < A.n_entries; i += (int32_t)blockDim.x) {
+                    rec[i].skip += base;
+                    if (!(rec[i].hit & kScreenLeaf)) rec[i].hit += base;
+                }
+            }
         } else if (A.lds_side) {   // RES_TOP: entry window | mats | texs
             size_t o2 = (((size_t)A.lds_entries * window_rec + 15) & ~(size_t)15);
             size_t o3 = o2 + (((size_t)A.n_mats * sizeof(Mat<real>) + 15) & ~(size_t)15);
