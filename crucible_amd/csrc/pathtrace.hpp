@@ -37,7 +37,28 @@ template <> struct RealTraits<double> {
 };
 
 CR_HD float r_sqrt(float x) { return __builtin_sqrtf(x); }
-CR_HD double r_sqrt(double x) { return __builtin_sqrt(x); }
+// f64 on the device: the compiler expands a correctly rounded square root into v_rsq_f64 and two Newton steps on
+// g ~ sqrt(x), h ~ 1/(2 sqrt(x)), wrapped in a scale-up of inputs below 2^-767, the scale-down of the result and a select for
+// 0 and +inf -- eight instructions that do nothing for an ordinary number.  When every active lane of the wave holds one (one
+// scalar branch), the same ten-instruction core runs without them and returns the same bits (tests/test_gpu_sqrt.py compares
+// the two on the device); any other wave takes the compiler's sequence.  The sphere test runs ~8 times per path segment.
+CR_HD double r_sqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t hi = (uint32_t)((unsigned long long)__builtin_bit_cast(long long, x) >> 32);
+    const bool ordinary = (hi - 0x10000000u) < (0x7ff00000u - 0x10000000u);   // 2^-767 <= x < +inf
+    if (__builtin_amdgcn_ballot_w64(!ordinary) == 0ull) {
+        const double y = __builtin_amdgcn_rsq(x);
+        double g = x * y, h = y * 0.5;
+        const double r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+        double d = __builtin_fma(-g, g, x);
+        g = __builtin_fma(d, h, g);
+        d = __builtin_fma(-g, g, x);
+        return __builtin_fma(d, h, g);
+    }
+#endif
+    return __builtin_sqrt(x);
+}
 CR_HD float r_abs(float x) { return __builtin_fabsf(x); }
 CR_HD double r_abs(double x) { return __builtin_fabs(x); }
 CR_HD float r_floor(float x) { return __builtin_floorf(x); }
@@ -956,8 +977,8 @@ template <int RES> CR_D uint32_t screen_lds_base(const void* lds) { return RES =
 template <int RES>
 CR_D ScreenEntry fetch_screen(const ScreenEntry* lds, const ScreenEntry* glob, uint32_t lds_bytes, uint32_t off) {
     static_assert(sizeof(ScreenEntry) == 32, "offsets are index << 5");
+    typedef uint32_t Quad __attribute__((ext_vector_type(4)));   // 16-byte aligned: two ds_read_b128 / global_load_dwordx4
     if (RES == RES_LDS) {   // the staged copy holds LDS addresses (screen_lds_base): `off` is one
-        typedef uint32_t Quad __attribute__((ext_vector_type(4)));   // 16-byte aligned: two ds_read_b128
         ScreenEntry e;
         Quad* o = reinterpret_cast<Quad*>(&e);
         LdsPtr<Quad> s = (LdsPtr<Quad>)(uintptr_t)off;
@@ -966,13 +987,13 @@ CR_D ScreenEntry fetch_screen(const ScreenEntry* lds, const ScreenEntry* glob, u
     }
     if (RES == RES_TOP) {
         ScreenEntry e;
-        uint32_t* o = reinterpret_cast<uint32_t*>(&e);
+        Quad* o = reinterpret_cast<Quad*>(&e);
         if (off < lds_bytes) {
-            LdsPtr<uint32_t> s = (LdsPtr<uint32_t>)(const void*)((const char*)lds + off);
-            for (int k = 0; k < 8; k++) o[k] = s[k];
+            LdsPtr<Quad> s = (LdsPtr<Quad>)(const void*)((const char*)lds + off);
+            o[0] = s[0]; o[1] = s[1];
         } else {
-            GlobPtr<uint32_t> s = (GlobPtr<uint32_t>)(const void*)((const char*)glob + off);
-            for (int k = 0; k < 8; k++) o[k] = s[k];
+            GlobPtr<Quad> s = (GlobPtr<Quad>)(const void*)((const char*)glob + off);
+            o[0] = s[0]; o[1] = s[1];
         }
         return e;
     }
