@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_short_sqrt_is_the_compilers_sqrt(tmp_path):
     exe = tmp_path / "sqrt_check"
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
-                    "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-function", "-I", os.path.join(ROOT, "crucible_amd", "csrc"),
+                    "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-function", "-Wno-unused-value", "-I", os.path.join(ROOT, "crucible_amd", "csrc"),
                     "-o", str(exe), os.path.join(ROOT, "tests", "sqrt_check.hip")], check=True, timeout=600)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
