@@ -479,7 +479,8 @@ def main():
         res_code = st["scene_in_lds"] if st["scene_in_lds"] is not None else 1
         anim = flat.desc.n_keys > 0
         cam_keyed = bool(cam.look_from_tl.keyframes() or cam.look_at_tl.keyframes())
-        screened = (not f32) and args.bvh != "ordered" and os.environ.get("CRUCIBLE_SCREEN", "1") != "0" and os.environ.get("CRUCIBLE_PIPELINE", "mega") == "mega" \
+        # f64: f32 screening records; f32, unordered trees: the wrappers in the same link layout
+        screened = not (f32 and args.bvh == "ordered") and os.environ.get("CRUCIBLE_SCREEN", "1") != "0" and os.environ.get("CRUCIBLE_PIPELINE", "mega") == "mega" \
             and not (res_code == 1 and os.environ.get("CRUCIBLE_SCREEN_LDS", "1") == "0")
         kname = (f"cr::pathtrace_kernel<{'float' if f32 else 'double'}, {res_code}, {b(anim)}, {b(args.bvh == 'ordered')}, "
                  f"{b(cam_keyed and not anim)}, {b(relaxed)}, {b(screened)}>")

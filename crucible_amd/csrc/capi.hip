@@ -535,11 +535,18 @@ int32_t make_screen(CrHandle* h, DevScene<double>& ds, const void* entries, DevB
     HIP_TRY(h, out.ensure((size_t)ds.n_entries * rec, ds.ordered ? entry_pad<ScreenEntryO>() : entry_pad<ScreenEntry>()));
     const dim3 grid((unsigned)((ds.n_entries + 255) / 256));
     if (ds.ordered) hipLaunchKernelGGL(screen_from_ordered_entries_kernel, grid, dim3(256), 0, h->stream, (const EntryO<double>*)entries, (ScreenEntryO*)out.p, ds.n_entries);
-    else hipLaunchKernelGGL(screen_from_entries_kernel, grid, dim3(256), 0, h->stream, (const Entry<double>*)entries, (ScreenEntry*)out.p, ds.n_entries);
+    else hipLaunchKernelGGL(screen_from_entries_kernel<double>, grid, dim3(256), 0, h->stream, (const Entry<double>*)entries, (ScreenEntry*)out.p, ds.n_entries);
     HIP_TRY(h, hipGetLastError());
     return CR_OK;
 }
-int32_t make_screen(CrHandle*, DevScene<float>&, const void*, DevBuf&) { return CR_OK; }
+// f32 scenes: the same boxes in ScreenEntry's link layout (the walk's inner loop reads that one), unordered trees only
+int32_t make_screen(CrHandle* h, DevScene<float>& ds, const void* entries, DevBuf& out) {
+    if (ds.ordered) { out.release(); return CR_OK; }
+    HIP_TRY(h, out.ensure((size_t)ds.n_entries * sizeof(ScreenEntry), entry_pad<ScreenEntry>()));
+    hipLaunchKernelGGL(screen_from_entries_kernel<float>, dim3((unsigned)((ds.n_entries + 255) / 256)), dim3(256), 0, h->stream, (const Entry<float>*)entries, (ScreenEntry*)out.p, ds.n_entries);
+    HIP_TRY(h, hipGetLastError());
+    return CR_OK;
+}
 
 template <typename real> int32_t build_dev_scene(CrHandle* h) {
     DevScene<real>& ds = dev_scene<real>(h);
@@ -874,13 +881,11 @@ template <typename real> int32_t build_dev_scene(CrHandle* h) {
         HIP_TRY(h, hipMemcpyAsync(b.entries.data(), ds.entries.p, b.entries.size() * sizeof(Entry<real>), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
-    if constexpr (std::is_same<real, double>::value) {
-        if (ds.n_entries > 0) {   // the f32 screening records (pathtrace.hpp walk_round)
-            int32_t rc = make_screen(h, ds, ds.entries.p, ds.screen);
-            if (rc != CR_OK) return rc;
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
-        } else ds.screen.release();
-    }
+    if (ds.n_entries > 0) {   // the f32 screening records of an f64 scene / the link-layout records of an f32 scene (pathtrace.hpp walk_round)
+        int32_t rc = make_screen(h, ds, ds.entries.p, ds.screen);
+        if (rc != CR_OK) return rc;
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    } else ds.screen.release();
     lap("uploads and boxes");
     ds.host_entries = b.entries;
     ds.host_axis = axis;
@@ -1360,16 +1365,13 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     }
     // f64 megakernel on an unordered tree: the walk decides its box tests on the f32 screening records (half the bytes
     // per step), see walk_round (A/B in profiles/experiments/r03_screen_ab.txt).
-    bool screen = false;
-    if constexpr (std::is_same<real, double>::value) {
-        screen = h->pipeline == 0 && ds.screen.p != nullptr && ds.n_entries > 0 && h->screen_boxes && (ds.ordered || ds.n_entries < kScreenMaxEntries);
-        if (screen) {
-            a.screen = ds.screen.p;
-            if (refit) {
-                int32_t rc = make_screen(h, ds, ds.entries_refit.p, ds.screen_refit);
-                if (rc != CR_OK) return rc;
-                a.screen = ds.screen_refit.p;
-            }
+    bool screen = h->pipeline == 0 && ds.screen.p != nullptr && ds.n_entries > 0 && h->screen_boxes && (ds.ordered || ds.n_entries < kScreenMaxEntries);
+    if (screen) {
+        a.screen = ds.screen.p;
+        if (refit) {
+            int32_t rc = make_screen(h, ds, ds.entries_refit.p, ds.screen_refit);
+            if (rc != CR_OK) return rc;
+            a.screen = ds.screen_refit.p;
         }
     }
     // a SCREEN kernel stages screening records where the others stage wrappers
@@ -1435,7 +1437,7 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     }
     if (ds.n_entries > 0 && (plain_lds || screen_lds)) {
         a.lds_entries = ds.n_entries;
-        if constexpr (std::is_same<real, double>::value) if (screen_lds) return launch_variant<real, RES_LDS, false, false, true>(h, a, lds_all_screen, stats, anim, cam_keys, relax);
+        if (screen_lds) return launch_variant<real, RES_LDS, false, false, true>(h, a, lds_all_screen, stats, anim, cam_keys, relax);
         a.screen = nullptr;
         return launch_variant<real, RES_LDS, false, false>(h, a, ds.lds_bytes, stats, anim, cam_keys, relax);
     }
@@ -1452,11 +1454,11 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
         const size_t side_cap = latency ? (((size_t)160 * 1024 / 3 - 16 > bytes + fx_lds_bytes(LatencyBlock, 4)) ? (size_t)160 * 1024 / 3 - 16 - bytes - fx_lds_bytes(LatencyBlock, 4) : 0) : h->lds_side_limit;
         if (side <= std::min(h->lds_side_limit, side_cap)) { a.lds_side = 1; bytes = ((bytes + 15) & ~(size_t)15) + side; }
         if constexpr (f32) if (latency) return launch_variant<real, RES_TOP, false, true>(h, a, bytes, stats, anim, cam_keys, relax);
-        if constexpr (!f32) if (screen) return launch_variant<real, RES_TOP, false, false, true>(h, a, bytes, stats, anim, cam_keys, relax);
+        if (screen) return launch_variant<real, RES_TOP, false, false, true>(h, a, bytes, stats, anim, cam_keys, relax);
         return launch_variant<real, RES_TOP, false, false>(h, a, bytes, stats, anim, cam_keys, relax);
     }
     a.lds_entries = 0;
-    if constexpr (!f32) if (screen) return launch_variant<real, RES_GLOBAL, false, false, true>(h, a, 0, stats, anim, cam_keys, relax);
+    if (screen) return launch_variant<real, RES_GLOBAL, false, false, true>(h, a, 0, stats, anim, cam_keys, relax);
     return launch_variant<real, RES_GLOBAL, false, false>(h, a, 0, stats, anim, cam_keys, relax);
 }
 

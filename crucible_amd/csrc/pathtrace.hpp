@@ -1070,7 +1070,9 @@ template <typename real, int RES, bool ANIM, bool ORD = false, bool SCREEN = fal
 CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, const Prim<real>* prims, V3<real> ro, V3<real> rd, real rtime,
                      WalkState<real>& w, bool walking, uint32_t budget, unsigned long long& c_node, uint32_t& c_prim, Diag* dg = nullptr,
                      const void* lds_screen = nullptr) {
-    static_assert(!SCREEN || std::is_same<real, double>::value, "screening records exist for the f64 kernels");
+    // f64: decisions on the f32 copy where f32 can decide; f32 (EXACT below): the record IS the wrapper's box, in the link layout of ScreenEntry
+    constexpr bool EXACT = std::is_same<real, float>::value;
+    static_assert(!(SCREEN && EXACT && ORD), "the f32 kernels use ScreenEntry records for unordered trees only");
     const real tmin = real(0.001);
     const int32_t n_entries = A.n_entries;
     // SCREEN kernels keep only screening records in LDS: the rare f64 record is read from global memory
@@ -1088,7 +1090,10 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
             const float mo = r_max(r_max(__builtin_fabsf(ofx), __builtin_fabsf(ofy)), __builtin_fabsf(ofz));
             const float pmax = r_max(r_max(__builtin_fabsf(ifx), __builtin_fabsf(ify)), __builtin_fabsf(ifz));
             const float pmin = r_min(r_min(__builtin_fabsf(ifx), __builtin_fabsf(ify)), __builtin_fabsf(ifz));
-            const bool screened = !w.exact_box && pmin >= 0x1.0p-100f && pmax <= 0x1.0p100f && mo <= 0x1.0p100f;
+            // (an f32 kernel's test on the record is Aabb::hit itself for every ray with finite 1/direction: no range to respect)
+            bool screened;
+            if constexpr (EXACT) screened = !w.exact_box;
+            else screened = !w.exact_box && pmin >= 0x1.0p-100f && pmax <= 0x1.0p100f && mo <= 0x1.0p100f;
             if (!screened) exact_steps = 0xffffffffu;
             else {
                 const float qx = __builtin_fabsf(ofx * ifx), qy = __builtin_fabsf(ofy * ify), qz = __builtin_fabsf(ofz * ifz);
@@ -1113,6 +1118,14 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
                     // loop-invariant tmaxf with a v_max_f32 x, x at every step (instruction selection works block by block and
                     // cannot see that it is a number), and one VALU instruction in this loop is about 1.5 % of the frame
                     float hi, m;
+                    if constexpr (EXACT) {
+                        nodes++;
+                        // f32 kernels: `max <= min -> miss` on the same operations as box_miss_fast (min(h, tmax) <= lo there is
+                        // h <= lo || tmax <= lo)
+                        asm("v_min_f32_e32 %0, %1, %2\n\tv_min3_f32 %0, %3, %4, %0" : "=&v"(hi) : "v"(fz), "v"(tmaxf), "v"(fx), "v"(fy));
+                        CR_DIAG_HIT(dg, DG_BOX_WAVE, DG_BOX_LANE);
+                        return hi <= lo;
+                    }
                     asm("v_min_f32_e32 %0, %2, %3\n\tv_min3_f32 %0, %4, %5, %0\n\tv_max_f32_e64 %1, |%6|, |%0|"
                         : "=&v"(hi), "=v"(m) : "v"(fz), "v"(tmaxf), "v"(fx), "v"(fy), "v"(lo));
                     const float th = __builtin_fmaf(0x1.0p-20f, m, th0);
@@ -1620,10 +1633,11 @@ pathtrace_kernel_latency(const KernelArgs<real> A) {
 
 // The screening records of a wrapper array: boxes rounded to the nearest f32 (the band of walk_round allows for either
 // direction), links copied.  Run after every upload and after every refit of the f64 boxes.
-__global__ void __launch_bounds__(256) screen_from_entries_kernel(const Entry<double>* e, ScreenEntry* s, int32_t n) {
+template <typename real>
+__global__ void __launch_bounds__(256) screen_from_entries_kernel(const Entry<real>* e, ScreenEntry* s, int32_t n) {
     const int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n) return;
-    const Entry<double> v = e[i];
+    const Entry<real> v = e[i];
     ScreenEntry o;
     for (int k = 0; k < 6; k++) o.b[k] = (float)v.b[k];
     o.skip = (uint32_t)v.skip << 5;
