@@ -492,12 +492,18 @@ CR_D bool triangle_t(V3<real> a, V3<real> b, V3<real> c, V3<real> o, V3<real> d,
     return true;
 }
 
-template <typename real> CR_D int32_t as_i32(real x) {   // Rust `as i32`: saturating, NaN -> 0
+// Rust `as i32`: truncation toward zero, saturating, NaN -> 0 -- which is what v_cvt_i32_f32 / v_cvt_i32_f64 do (ISA: out-of-range
+// values and infinities saturate, NaN converts to 0).  Written as the instruction: C++'s cast is undefined out of range, and the
+// guarded form costs three compares and their branches per conversion (the checker texture makes three per hit).
+// tests/sqrt_check.hip compares it with as_i32_reference on the device.
+template <typename real> CR_HD int32_t as_i32_reference(real x) {
     if (!(x == x)) return 0;
     if (x <= real(-2147483648.0)) return INT32_MIN;
     if (x >= real(2147483647.0)) return INT32_MAX;
     return (int32_t)x;
 }
+CR_D int32_t as_i32(float x) { int32_t r; asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+CR_D int32_t as_i32(double x) { int32_t r; asm("v_cvt_i32_f64_e32 %0, %1" : "=v"(r) : "v"(x)); return r; }
 template <typename real> CR_D uint32_t as_index(real x, int32_t n) {   // `as usize` then clamp to n-1 (img_loader.rs:72-73)
     if (!(x == x) || x <= real(0)) return 0;
     if (x >= (real)n) return (uint32_t)(n - 1);
