@@ -1365,7 +1365,7 @@ int32_t render_typed(CrHandle* h, const CrCameraDesc* cd, const CrRenderParams* 
     }
     // f64 megakernel on an unordered tree: the walk decides its box tests on the f32 screening records (half the bytes
     // per step), see walk_round (A/B in profiles/experiments/r03_screen_ab.txt).
-    bool screen = h->pipeline == 0 && ds.screen.p != nullptr && ds.n_entries > 0 && h->screen_boxes && (ds.ordered || ds.n_entries < kScreenMaxEntries);
+    bool screen = h->pipeline == 0 && ds.screen.p != nullptr && ds.n_entries > 0 && h->screen_boxes && ds.n_entries < (ds.ordered ? kScreenMaxEntriesO : kScreenMaxEntries);
     if (screen) {
         a.screen = ds.screen.p;
         if (refit) {

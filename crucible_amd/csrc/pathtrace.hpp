@@ -202,12 +202,17 @@ struct alignas(16) ScreenEntry {
 constexpr uint32_t kScreenLeaf = 0x80000000u;
 constexpr int32_t kScreenMaxEntries = 1 << 26;   // offsets stay below bit 31
 // ... and of an EntryO (CR_BVH_SAH_ORDERED): 64 bytes instead of 96.
+// Links as in ScreenEntry (byte offsets into this array, index * 64): `hit` = the LEFT child's offset or kScreenLeaf | leaf
+// code, `axis` = the split axis (3 for a leaf), `skip[o]` = the wrapper after a miss for a ray of direction octant o.  The
+// near child is one bit-field extract and one shift-add away: hit + (((octant >> axis) & 1) << 6) -- and a leaf's axis 3 selects
+// a bit no octant has, so the same two instructions leave its code alone.
 struct alignas(16) ScreenEntryO {
     float b[6];
-    int32_t unused;
-    int32_t leaf;
-    int32_t skip[8];
+    uint32_t axis;
+    uint32_t hit;
+    uint32_t skip[8];
 };
+constexpr int32_t kScreenMaxEntriesO = 1 << 25;   // offsets stay below bit 31
 template <bool ORD> struct ScreenOf { using type = ScreenEntry; };
 template <> struct ScreenOf<true> { using type = ScreenEntryO; };
 constexpr int32_t kLeafRun = 0x40000000;
@@ -1006,22 +1011,32 @@ CR_D ScreenEntry fetch_screen(const ScreenEntry* lds, const ScreenEntry* glob, u
     return *(const ScreenEntry*)((const char*)glob + off);
 }
 
-// The ordered layout's screening record read into the same shape: skip = the link of the ray's octant.
-struct ScreenStep { float b[6]; int32_t skip; int32_t leaf; };
+// The ordered layout's screening record by its byte offset: the box, {axis, hit} and the skip link of the ray's octant
+// (octoff = 32 + 4 * octant, the byte offset of skip[octant] in the record).
+struct ScreenStepO { float b[6]; uint32_t axis, hit, skip; };
 template <int RES>
-CR_D ScreenStep fetch_screen_ordered(const ScreenEntryO* lds, const ScreenEntryO* glob, int32_t lds_n, int32_t idx, int32_t oct) {
-    ScreenStep e;
-    if (RES == RES_LDS || (RES == RES_TOP && idx < lds_n)) {
-        const ScreenEntryO* s = lds + idx;
-        LdsPtr<float> b = (LdsPtr<float>)s->b;
-        for (int k = 0; k < 6; k++) e.b[k] = b[k];
-        e.leaf = *(LdsPtr<int32_t>)&s->leaf; e.skip = ((LdsPtr<int32_t>)s->skip)[oct];
+CR_D ScreenStepO fetch_screen_ordered(const ScreenEntryO* lds, const ScreenEntryO* glob, uint32_t lds_bytes, uint32_t off, uint32_t octoff) {
+    static_assert(sizeof(ScreenEntryO) == 64, "offsets are index << 6");
+    typedef uint32_t Quad __attribute__((ext_vector_type(4)));
+    ScreenStepO e;
+    Quad q0, q1;
+    if (RES == RES_LDS) {   // the staged copy holds LDS addresses: `off` is one
+        LdsPtr<Quad> s = (LdsPtr<Quad>)(uintptr_t)off;
+        q0 = s[0]; q1 = s[1];
+        e.skip = *(LdsPtr<uint32_t>)(uintptr_t)(off + octoff);
+    } else if (RES == RES_TOP && off < lds_bytes) {
+        LdsPtr<Quad> s = (LdsPtr<Quad>)(const void*)((const char*)lds + off);
+        q0 = s[0]; q1 = s[1];
+        e.skip = *(LdsPtr<uint32_t>)(const void*)((const char*)lds + off + octoff);
     } else {
-        const ScreenEntryO* s = glob + idx;
-        GlobPtr<float> b = (GlobPtr<float>)s->b;
-        for (int k = 0; k < 6; k++) e.b[k] = b[k];
-        e.leaf = *(GlobPtr<int32_t>)&s->leaf; e.skip = ((GlobPtr<int32_t>)s->skip)[oct];
+        GlobPtr<Quad> s = (GlobPtr<Quad>)(const void*)((const char*)glob + off);
+        q0 = s[0]; q1 = s[1];
+        e.skip = *(GlobPtr<uint32_t>)(const void*)((const char*)glob + off + octoff);
     }
+    uint32_t w[8];
+    __builtin_memcpy(w, &q0, 16); __builtin_memcpy(w + 4, &q1, 16);
+    for (int k = 0; k < 6; k++) e.b[k] = __builtin_bit_cast(float, w[k]);
+    e.axis = w[6]; e.hit = w[7];
     return e;
 }
 
@@ -1153,13 +1168,24 @@ CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, 
                 };
                 // `it` is the same in every lane still in the loop (a scalar register)
                 if constexpr (ORD) {
-                    for (uint32_t it = 0; w.idx < n_entries; it++) {
-                        const ScreenStep se = fetch_screen_ordered<RES>((const ScreenEntryO*)lds_screen, (const ScreenEntryO*)A.screen, A.lds_entries, w.idx, w.oct);
-                        const bool miss = box_miss(se.b, w.idx);
-                        const bool inner = se.leaf < 0;
-                        w.idx = (inner && !miss) ? ordered_near(se.leaf, w.oct) : se.skip;
-                        if (!(miss || inner)) { leaf = se.leaf; break; }
-                        if (it + 1 == budget) break;
+                    // near child first: the same loop on ScreenEntryO records -- the skip link is the octant's, the hit link the left
+                    // child's plus one record when the ray points down the split axis
+                    const uint32_t base = screen_lds_base<RES>(lds_screen);
+                    const uint32_t end = base + ((uint32_t)n_entries << 6);
+                    const uint32_t oct = (uint32_t)w.oct, octoff = 32u + (oct << 2);
+                    uint32_t off = base + ((uint32_t)w.idx << 6), after_leaf = 0;
+                    if (off < end) {
+                        for (uint32_t it = 0;; it++) {
+                            const ScreenStepO se = fetch_screen_ordered<RES>((const ScreenEntryO*)lds_screen, (const ScreenEntryO*)A.screen, (uint32_t)A.lds_entries << 6, off, octoff);
+                            const bool miss = box_miss(se.b, (int32_t)((off - base) >> 6));
+                            after_leaf = se.skip;
+                            off = miss ? se.skip : se.hit + (__builtin_amdgcn_ubfe(oct, se.axis, 1u) << 6);
+                            uint32_t limit = (it + 1 == budget) ? 0u : end;   // (as below)
+                            asm("" : "+s"(limit));
+                            if (off >= limit) break;
+                        }
+                        if (off & kScreenLeaf) { leaf = (int32_t)(off & ~kScreenLeaf); off = after_leaf; }
+                        w.idx = (int32_t)((off - base) >> 6);
                     }
                 } else {
                     // the lane's position as a byte offset into the record array (ScreenEntry): a lane leaves the loop at the
@@ -1329,12 +1355,13 @@ CR_D void pathtrace_body(const KernelArgs<real>& A) {
             prims = (const Prim<real>*)(smem + o1);
             mats = (const Mat<real>*)(smem + o2);
             texs = (const Tex<real>*)(smem + o3);
-            if constexpr (SCREEN && !ORD) {   // links of the staged screening records become LDS addresses (fetch_screen)
+            if constexpr (SCREEN) {   // links of the staged screening records become LDS addresses (fetch_screen, fetch_screen_ordered)
                 __syncthreads();
                 const uint32_t base = screen_lds_base<RES>(smem);
-                ScreenEntry* rec = (ScreenEntry*)smem;
+                ScreenT* rec = (ScreenT*)smem;
                 for (int32_t i = (int32_t)threadIdx.x; i < A.n_entries; i += (int32_t)blockDim.x) {
-                    rec[i].skip += base;
+                    if constexpr (ORD) { for (int k = 0; k < 8; k++) rec[i].skip[k] += base; }
+                    else rec[i].skip += base;
                     if (!(rec[i].hit & kScreenLeaf)) rec[i].hit += base;
                 }
             }
@@ -1657,8 +1684,9 @@ __global__ void __launch_bounds__(256) screen_from_ordered_entries_kernel(const 
     const EntryO<double> v = e[i];
     ScreenEntryO o;
     for (int k = 0; k < 6; k++) o.b[k] = (float)v.b[k];
-    o.unused = 0; o.leaf = v.leaf;
-    for (int k = 0; k < 8; k++) o.skip[k] = v.skip[k];
+    if (v.leaf < 0) { o.axis = (uint32_t)(-v.leaf) & 3u; o.hit = (uint32_t)ordered_left(v.leaf) << 6; }
+    else { o.axis = 3u; o.hit = kScreenLeaf | (uint32_t)v.leaf; }
+    for (int k = 0; k < 8; k++) o.skip[k] = (uint32_t)v.skip[k] << 6;
     s[i] = o;
 }
 
