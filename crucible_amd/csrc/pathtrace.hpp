@@ -1068,7 +1068,9 @@ template <typename real> CR_D void walk_begin(WalkState<real>& w, V3<real> rd) {
 // Per lane this is exactly BVHWrapper::hit's sequence (bvhwrapper.rs:96-126); the round structure only decides
 // when lanes wait for each other.
 // ORD: the ordered layout (EntryO behind the same pointers) -- near child first, per-octant skip links.
-// f64, unordered trees, A.screen set: Aabb::hit decided on the f32 screening record wherever f32 can decide it.
+// SCREEN kernels walk on the 32-byte ScreenEntry (64-byte ScreenEntryO) records: byte-offset links in the form the loop consumes.
+// f32 kernels (unordered trees): the record holds the wrapper's own box and the test on it is Aabb::hit (EXACT below).
+// f64 kernels: Aabb::hit decided on the f32 screening record wherever f32 can decide it:
 // Notation: b, o, inv = an f64 box plane, the origin component and 1/direction on that axis; bf, of, if their f32
 // roundings; u = 2^-24; T = (b - o) * inv; t32 = fl(fl(bf - of) * if) the f32 slab distance.  Then
 //     |t32 - T| <= 1.01 u |inv| (|b| + |o|) + 3.01 u |t32|          (three roundings of inputs, two of operations)
@@ -1084,8 +1086,8 @@ template <typename real> CR_D void walk_begin(WalkState<real>& w, V3<real> rd) {
 // `max <= min` (a miss), hi32 - lo32 > TH proves a hit, and only a lane with |hi32 - lo32| <= TH evaluates Aabb::hit in f64
 // on the f64 box.  Overflow and NaN land there too (every comparison with them is false), and the round uses the screen only
 // when |if| lies in [2^-100, 2^100] and |of| <= 2^100 on every axis.  The decisions -- hence the walk, the counters and the image -- are those of the f64 test.
-// SCREEN is a kernel variant of its own (f64, unordered trees read from global memory): a kernel that carried both the
-// f32 loop and the f64 min/max loop lost 5 % on the teapot frames to register pressure.  In a SCREEN kernel a ray whose
+// SCREEN is a kernel variant of its own: a kernel that carried both the f32 loop and the f64 min/max loop lost 5 % on the
+// teapot frames to register pressure.  In a SCREEN kernel a ray whose
 // 1/direction is infinite, or outside the f32 range above, walks with Aabb::hit's compare/select form (valid for every ray).
 template <typename real, int RES, bool ANIM, bool ORD = false, bool SCREEN = false>
 CR_D void walk_round(const KernelArgs<real>& A, const Entry<real>* lds_entries, const Prim<real>* prims, V3<real> ro, V3<real> rd, real rtime,
